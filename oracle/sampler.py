@@ -1,0 +1,82 @@
+"""Oracle: sampler arithmetic and loops, CPU fp32 (test infrastructure only).
+
+Restates, for the configured mode START_X + FIXED_SMALL (utils/model_util.py:37-72),
+reference `diffusion/gaussian_diffusion.py`:
+  q_sample :233-251, q_posterior_mean_variance :253-275, p_mean_variance :277-388
+  (incl. the inpainting blend :307-311), _predict_eps_from_xstart :407-411,
+  p_sample :496-548, p_sample_loop{,_progressive} :598-730, ddim_sample :732-782,
+  ddim_sample_loop{,_progressive} :879-993, _extract_into_tensor :1595-1608,
+and `diffusion/respace.py:117-129` (_WrappedModel timestep mapping).
+
+The reference draws its Gaussians from torch's global generator; the oracle replays
+an explicit *noise tape* ``[x_T, z_{N-1}, ..., z_0]`` instead so CPU/GPU runs see the
+same numbers.  Pinned by tests/golden/loops_*.npz.
+"""
+import torch
+
+
+def extract(arr, t):
+    """_extract_into_tensor: fp64 table -> gather -> .float() -> [B,1,1,1]."""
+    return torch.from_numpy(arr)[t].float().view(-1, 1, 1, 1)
+
+
+def q_sample(tab, x_start, t, noise):
+    return extract(tab.sqrt_alphas_cumprod, t) * x_start + extract(tab.sqrt_one_minus_alphas_cumprod, t) * noise
+
+
+def inpaint(x0, y):
+    if "inpainting_mask" in y and "inpainted_motion" in y:
+        m = y["inpainting_mask"]
+        return (x0 * ~m) + (y["inpainted_motion"] * m)
+    return x0
+
+
+def p_sample_step(tab, x0, x, t, noise):
+    """Ancestral update given the model's x0 prediction (FIXED_SMALL variance)."""
+    mean = extract(tab.posterior_mean_coef1, t) * x0 + extract(tab.posterior_mean_coef2, t) * x
+    log_var = extract(tab.posterior_log_variance_clipped, t)
+    nonzero = (t != 0).float().view(-1, 1, 1, 1)
+    return mean + nonzero * torch.exp(0.5 * log_var) * noise
+
+
+def ddim_step(tab, x0, x, t, noise, eta=0.0):
+    eps = (extract(tab.sqrt_recip_alphas_cumprod, t) * x - x0) / extract(tab.sqrt_recipm1_alphas_cumprod, t)
+    ab = extract(tab.alphas_cumprod, t)
+    ab_prev = extract(tab.alphas_cumprod_prev, t)
+    sigma = eta * torch.sqrt((1 - ab_prev) / (1 - ab)) * torch.sqrt(1 - ab / ab_prev)
+    mean = x0 * torch.sqrt(ab_prev) + torch.sqrt(1 - ab_prev - sigma ** 2) * eps
+    nonzero = (t != 0).float().view(-1, 1, 1, 1)
+    return mean + nonzero * sigma * noise
+
+
+def sample_loop(model_fn, tab, tmap, shape, tape, y, kind="p", eta=0.0, skip_timesteps=0,
+                init_image=None, const_noise=False, dump_steps=None):
+    """Drive `model_fn(x, mapped_t, y) -> x0` through the whole reverse process.
+
+    tape: list/tensor of N+1 noise tensors, tape[0] = x_T, tape[1+k] = z of the k-th
+    executed step (reference draws in exactly this order).
+    Returns the final sample (or the list of dumped steps, ancestral only).
+    """
+    B = shape[0]
+    img = tape[0]
+    if skip_timesteps and init_image is None:
+        init_image = torch.zeros_like(img)
+    indices = list(range(tab.num_timesteps - skip_timesteps))[::-1]
+    if init_image is not None:
+        my_t = torch.ones(B, dtype=torch.long) * indices[0]
+        img = q_sample(tab, init_image, my_t, img)
+    map_tensor = torch.tensor(tmap, dtype=torch.long)
+    dump = []
+    for k, i in enumerate(indices):
+        t = torch.tensor([i] * B)
+        x0 = inpaint(model_fn(img, map_tensor[t], y), y)
+        z = tape[1 + k]
+        if kind == "p":
+            if const_noise:
+                z = z[[0]].repeat(B, 1, 1, 1)
+            img = p_sample_step(tab, x0, img, t, z)
+        else:
+            img = ddim_step(tab, x0, img, t, z, eta)
+        if dump_steps is not None and k in dump_steps:
+            dump.append(img.clone())
+    return dump if dump_steps is not None else img
