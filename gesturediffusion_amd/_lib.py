@@ -1,0 +1,99 @@
+"""ctypes binding of libgdx.so (C ABI: include/gdx.h).
+
+The product path has NO fallback: if the HIP library is missing or fails to load, every
+compute entry point raises.  Build it with ``python __graft_entry__.py`` (or
+``make -C gesturediffusion_amd/csrc``); the .so stays in-tree next to its sources.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libgdx.so")
+
+GDX_ARCH_MDM_OLD, GDX_ARCH_MDM = 1, 2
+GDX_COND, GDX_UNCOND, GDX_CFG = 0, 1, 2
+GDX_SAMPLER_P, GDX_SAMPLER_DDIM = 0, 1
+
+EXPORTS = [
+    "gdx_create", "gdx_destroy", "gdx_last_error", "gdx_set_weight", "gdx_weights_ready", "gdx_prepare",
+    "gdx_set_condition", "gdx_forward", "gdx_set_keep_taps", "gdx_get_tap", "gdx_sampler_update", "gdx_q_sample",
+    "gdx_randn", "gdx_sample_loop", "gdx_bench_ffn_gemm", "gdx_forward_flops",
+]
+
+
+class GdxError(RuntimeError):
+    pass
+
+
+class Config(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("arch", "njoints", "latent_dim", "ff_size", "num_layers", "num_heads",
+                                         "seed_poses", "mfcc_dim", "cl_head", "window")]
+
+
+class UpdateArgs(C.Structure):
+    _fields_ = [
+        ("kind", C.c_int32), ("batch", C.c_int32), ("njoints", C.c_int32), ("frames", C.c_int32),
+        ("coef", C.c_void_p), ("t", C.c_void_p), ("step_index", C.c_int32),
+        ("x", C.c_void_p), ("x0_cond", C.c_void_p), ("x0_uncond", C.c_void_p), ("scale", C.c_void_p),
+        ("inpaint_mask", C.c_void_p), ("inpaint_motion", C.c_void_p), ("noise", C.c_void_p),
+        ("const_noise", C.c_int32), ("philox_seed", C.c_uint64), ("sample_offset", C.c_uint64),
+        ("rng_step", C.c_uint32), ("out", C.c_void_p), ("pred_xstart", C.c_void_p),
+    ]
+
+
+class LoopArgs(C.Structure):
+    _fields_ = [
+        ("kind", C.c_int32), ("mode", C.c_int32), ("num_steps", C.c_int32), ("first_index", C.c_int32),
+        ("coef", C.c_void_p), ("timestep_map", C.c_void_p), ("x", C.c_void_p), ("scale", C.c_void_p),
+        ("inpaint_mask", C.c_void_p), ("inpaint_motion", C.c_void_p), ("noise_tape", C.c_void_p),
+        ("const_noise", C.c_int32), ("philox_seed", C.c_uint64), ("sample_offset", C.c_uint64),
+        ("dump", C.c_void_p), ("dump_steps", C.c_void_p), ("n_dump", C.c_int32),
+    ]
+
+
+_lib = None
+
+
+def load():
+    """Load libgdx.so once; raise GdxError (never fall back) when it is unavailable."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise GdxError(f"HIP library not built: {LIB_PATH} is missing "
+                       f"(run `python __graft_entry__.py` or `make -C gesturediffusion_amd/csrc`)")
+    try:
+        lib = C.CDLL(LIB_PATH)
+    except OSError as e:  # missing libamdhip64, wrong arch ...
+        raise GdxError(f"cannot load {LIB_PATH}: {e}") from e
+    vp, i32, i64, u64, u32 = C.c_void_p, C.c_int32, C.c_int64, C.c_uint64, C.c_uint32
+    lib.gdx_last_error.restype = C.c_char_p
+    sigs = {
+        "gdx_create": [C.POINTER(Config), C.POINTER(vp)],
+        "gdx_destroy": [vp],
+        "gdx_set_weight": [vp, C.c_char_p, vp, C.POINTER(i64), i32, vp],
+        "gdx_weights_ready": [vp],
+        "gdx_prepare": [vp, i32, i32],
+        "gdx_set_condition": [vp, vp, vp, vp],
+        "gdx_forward": [vp, vp, vp, i32, vp, vp, vp],
+        "gdx_set_keep_taps": [vp, i32],
+        "gdx_get_tap": [vp, i32, vp, i64, vp],
+        "gdx_sampler_update": [C.POINTER(UpdateArgs), vp],
+        "gdx_q_sample": [vp, vp, vp, i32, i64, vp, vp],
+        "gdx_randn": [vp, i32, i64, u64, u64, u32, vp],
+        "gdx_sample_loop": [vp, C.POINTER(LoopArgs), vp],
+        "gdx_bench_ffn_gemm": [vp, i32, C.POINTER(C.c_float), vp],
+        "gdx_forward_flops": [vp, i32, C.POINTER(C.c_double)],
+    }
+    for name, args in sigs.items():
+        fn = getattr(lib, name)
+        fn.argtypes = args
+        fn.restype = i32
+    _lib = lib
+    return lib
+
+
+def check(rc, lib=None):
+    if rc != 0:
+        lib = lib or load()
+        raise GdxError(lib.gdx_last_error().decode() or f"libgdx error {rc}")

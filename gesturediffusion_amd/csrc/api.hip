@@ -1,0 +1,542 @@
+// libgdx.so host side: handle, packed weights, workspace, the per-step kernel sequence of the
+// denoiser (V1 = reference model/mdm_old.py:84-122, V2 = model/mdm.py:105-224) and the sampling
+// loops (diffusion/gaussian_diffusion.py:598-730, 879-993).  C ABI in include/gdx.h.
+#include "gdx_internal.h"
+#include "../../include/gdx.h"
+
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <set>
+#include <string>
+#include <vector>
+
+namespace gdx {
+
+static thread_local std::string g_err;
+
+static int fail(const std::string& m) {
+    g_err = m;
+    return -1;
+}
+#define HIPCHK(expr)                                                                       \
+    do {                                                                                   \
+        hipError_t e_ = (expr);                                                            \
+        if (e_ != hipSuccess) return fail(std::string(#expr) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+static inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+// dst[r][c] = (r < n && c < k) ? src[r*src_ld + col0 + c] : 0      (dst is [npad][kpad])
+__global__ void pack_weight_kernel(const float* __restrict__ src, int src_ld, int col0, int n, int k,
+                                   float* __restrict__ dst, int npad, int kpad) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)npad * kpad) return;
+    const int r = i / kpad, c = i % kpad;
+    dst[i] = (r < n && c < k) ? src[(long)r * src_ld + col0 + c] : 0.0f;
+}
+
+struct Packed {          // a Linear weight [n][k] packed to [npad][kpad] (+ bias [npad])
+    float* w = nullptr;
+    float* bias = nullptr;
+    int n = 0, k = 0, npad = 0, kpad = 0;
+};
+
+struct Layer {
+    Packed qkv, out, ff1, ff2;
+    float *g1 = nullptr, *b1 = nullptr, *g2 = nullptr, *b2 = nullptr;
+};
+
+}  // namespace gdx
+
+using namespace gdx;
+
+struct gdx_model {
+    gdx_config_t cfg;
+    int d, J, ff, L, H;
+    std::set<std::string> have;
+    std::vector<std::string> required;
+    std::vector<void*> allocs;        // weight allocations
+    std::vector<void*> ws_allocs;     // workspace allocations
+    Packed time0, time2, seed, in_x, in_mfcc, proj_pose, proj_audio, proj_coa, outp;
+    std::vector<Layer> layers;
+    float* pe = nullptr; int pe_rows = 0;
+    float *rope_cos = nullptr, *rope_sin = nullptr; int rope_rows = 0;
+    // workspace (sized for 2*B samples so that CFG runs as one double batch)
+    int B = 0, T = 0, S = 0;
+    bool cond_set = false;
+    float *xa = nullptr, *xb = nullptr, *qkv = nullptr, *ctx = nullptr, *tmp = nullptr, *ffb = nullptr;
+    float *emb_pose = nullptr, *xseq = nullptr, *addend = nullptr;
+    float *seed_cat = nullptr, *temb_in = nullptr, *temb_h = nullptr, *temb = nullptr, *coa = nullptr, *c2 = nullptr;
+    float* x0 = nullptr;              // [2B, J, T]
+    float* temb_table = nullptr; int temb_table_rows = 0;
+    int64_t* tmap_dev = nullptr;
+    bool keep_taps = false;
+    std::vector<float*> taps;         // [L+1] x [2B*S*d] when keep_taps
+};
+
+static int dev_alloc(std::vector<void*>& pool, void** p, size_t bytes) {
+    hipError_t e = hipMalloc(p, bytes ? bytes : 16);
+    if (e != hipSuccess) return fail(std::string("hipMalloc: ") + hipGetErrorString(e));
+    pool.push_back(*p);
+    return 0;
+}
+
+static int pack(gdx_model* h, Packed& P, const float* src, int n, int src_ld, int col0, int k, hipStream_t s) {
+    P.n = n; P.k = k; P.npad = round_up(n, 128); P.kpad = round_up(k, 32);
+    if (!P.w && dev_alloc(h->allocs, (void**)&P.w, sizeof(float) * P.npad * (size_t)P.kpad)) return -1;
+    const long total = (long)P.npad * P.kpad;
+    hipLaunchKernelGGL(pack_weight_kernel, dim3((total + 255) / 256), dim3(256), 0, s, src, src_ld, col0, n, k, P.w,
+                       P.npad, P.kpad);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+static int pack_vec(gdx_model* h, float** dst, const float* src, int n, int npad, hipStream_t s) {
+    if (!*dst && dev_alloc(h->allocs, (void**)dst, sizeof(float) * npad)) return -1;
+    HIPCHK(hipMemsetAsync(*dst, 0, sizeof(float) * npad, s));
+    HIPCHK(hipMemcpyAsync(*dst, src, sizeof(float) * n, hipMemcpyDeviceToDevice, s));
+    return 0;
+}
+
+extern "C" int gdx_set_error_(const char* msg) { return fail(msg); }
+
+extern "C" const char* gdx_last_error(void) { return g_err.c_str(); }
+
+extern "C" int gdx_create(const gdx_config_t* cfg, gdx_handle_t* out) {
+    if (!cfg || !out) return fail("gdx_create: null argument");
+    if (cfg->arch != GDX_ARCH_MDM && cfg->arch != GDX_ARCH_MDM_OLD) return fail("gdx_create: unknown arch");
+    if (cfg->latent_dim <= 0 || cfg->latent_dim % 32) return fail("gdx_create: latent_dim must be a multiple of 32");
+    if (cfg->ff_size <= 0 || cfg->ff_size % 32) return fail("gdx_create: ff_size must be a multiple of 32");
+    if (cfg->num_heads <= 0 || cfg->latent_dim % cfg->num_heads) return fail("gdx_create: latent_dim % num_heads != 0");
+    const int hd = cfg->latent_dim / cfg->num_heads;
+    if (hd != 32 && hd != 64 && hd != 128 && hd != 256) return fail("gdx_create: head_dim must be 32/64/128/256");
+    if (cfg->njoints <= 0 || cfg->num_layers <= 0 || cfg->seed_poses <= 0 || cfg->mfcc_dim <= 0 || cfg->mfcc_dim > 32)
+        return fail("gdx_create: bad njoints/num_layers/seed_poses/mfcc_dim");
+    if (cfg->arch == GDX_ARCH_MDM) {
+        if (cfg->cl_head <= 0 || cfg->latent_dim % cfg->cl_head || (cfg->latent_dim / cfg->cl_head) % 2)
+            return fail("gdx_create: latent_dim / cl_head must be an even integer");
+        if (cfg->window <= 0 || cfg->window > 16) return fail("gdx_create: window must be in 1..16");
+    }
+    hipError_t e = gemm_init();
+    if (e != hipSuccess) return fail(std::string("gemm_init: ") + hipGetErrorString(e));
+    gdx_model* h = new gdx_model();
+    h->cfg = *cfg;
+    h->d = cfg->latent_dim; h->J = cfg->njoints; h->ff = cfg->ff_size; h->L = cfg->num_layers; h->H = cfg->num_heads;
+    h->layers.resize(h->L);
+    auto& r = h->required;
+    for (const char* n : {"embed_timestep.time_embed.0.weight", "embed_timestep.time_embed.0.bias",
+                          "embed_timestep.time_embed.2.weight", "embed_timestep.time_embed.2.bias",
+                          "seed_pose_encoder.seed_embed.weight", "seed_pose_encoder.seed_embed.bias",
+                          "input_process.poseEmbedding.weight", "input_process.poseEmbedding.bias",
+                          "output_process.poseFinal.weight", "output_process.poseFinal.bias", "sequence_pos_encoder.pe"})
+        r.push_back(n);
+    if (cfg->arch == GDX_ARCH_MDM)
+        for (const char* n : {"project_to_lat.weight", "project_to_lat.bias", "rope.cos", "rope.sin"}) r.push_back(n);
+    for (int l = 0; l < h->L; ++l) {
+        const std::string p = "seqTransEncoder.layers." + std::to_string(l) + ".";
+        for (const char* n : {"self_attn.in_proj_weight", "self_attn.in_proj_bias", "self_attn.out_proj.weight",
+                              "self_attn.out_proj.bias", "linear1.weight", "linear1.bias", "linear2.weight",
+                              "linear2.bias", "norm1.weight", "norm1.bias", "norm2.weight", "norm2.bias"})
+            r.push_back(p + n);
+    }
+    *out = h;
+    return 0;
+}
+
+static void free_pool(std::vector<void*>& pool) {
+    for (void* p : pool) (void)hipFree(p);
+    pool.clear();
+}
+
+extern "C" int gdx_destroy(gdx_handle_t h) {
+    if (!h) return 0;
+    free_pool(h->allocs);
+    free_pool(h->ws_allocs);
+    delete h;
+    return 0;
+}
+
+static bool shape_is(const int64_t* shape, int ndim, std::initializer_list<int64_t> want) {
+    if (ndim != (int)want.size()) return false;
+    int i = 0;
+    for (int64_t w : want)
+        if (shape[i++] != w) return false;
+    return true;
+}
+
+extern "C" int gdx_set_weight(gdx_handle_t h, const char* name_c, const float* p, const int64_t* shape, int32_t ndim,
+                              void* stream) {
+    if (!h || !name_c || !p || !shape) return fail("gdx_set_weight: null argument");
+    hipStream_t s = (hipStream_t)stream;
+    const std::string name(name_c);
+    const int d = h->d, J = h->J, ff = h->ff, mf = h->cfg.mfcc_dim;
+    auto bad = [&]() { return fail("gdx_set_weight: unexpected shape for " + name); };
+    int rc = 0;
+    if (name == "embed_timestep.time_embed.0.weight") {
+        if (!shape_is(shape, ndim, {d, d})) return bad();
+        rc = pack(h, h->time0, p, d, d, 0, d, s);
+    } else if (name == "embed_timestep.time_embed.0.bias") {
+        if (!shape_is(shape, ndim, {d})) return bad();
+        rc = pack_vec(h, &h->time0.bias, p, d, round_up(d, 128), s);
+    } else if (name == "embed_timestep.time_embed.2.weight") {
+        if (!shape_is(shape, ndim, {d, d})) return bad();
+        rc = pack(h, h->time2, p, d, d, 0, d, s);
+    } else if (name == "embed_timestep.time_embed.2.bias") {
+        if (!shape_is(shape, ndim, {d})) return bad();
+        rc = pack_vec(h, &h->time2.bias, p, d, round_up(d, 128), s);
+    } else if (name == "seed_pose_encoder.seed_embed.weight") {
+        const int k = J * h->cfg.seed_poses;
+        if (!shape_is(shape, ndim, {d, k})) return bad();
+        rc = pack(h, h->seed, p, d, k, 0, k, s);
+    } else if (name == "seed_pose_encoder.seed_embed.bias") {
+        if (!shape_is(shape, ndim, {d})) return bad();
+        rc = pack_vec(h, &h->seed.bias, p, d, round_up(d, 128), s);
+    } else if (name == "input_process.poseEmbedding.weight") {
+        if (h->cfg.arch == GDX_ARCH_MDM) {
+            if (!shape_is(shape, ndim, {d, J})) return bad();
+            rc = pack(h, h->in_x, p, d, J, 0, J, s);
+        } else {
+            if (!shape_is(shape, ndim, {d, J + mf})) return bad();
+            rc = pack(h, h->in_x, p, d, J + mf, 0, J, s);
+            if (!rc) rc = pack(h, h->in_mfcc, p, d, J + mf, J, mf, s);
+        }
+    } else if (name == "input_process.poseEmbedding.bias") {
+        if (!shape_is(shape, ndim, {d})) return bad();
+        rc = pack_vec(h, &h->in_x.bias, p, d, round_up(d, 128), s);
+    } else if (name == "project_to_lat.weight" && h->cfg.arch == GDX_ARCH_MDM) {
+        if (!shape_is(shape, ndim, {d, 2 * d + mf})) return bad();
+        rc = pack(h, h->proj_pose, p, d, 2 * d + mf, 0, d, s);
+        if (!rc) rc = pack(h, h->proj_audio, p, d, 2 * d + mf, d, mf, s);
+        if (!rc) rc = pack(h, h->proj_coa, p, d, 2 * d + mf, d + mf, d, s);
+    } else if (name == "project_to_lat.bias" && h->cfg.arch == GDX_ARCH_MDM) {
+        if (!shape_is(shape, ndim, {d})) return bad();
+        rc = pack_vec(h, &h->proj_pose.bias, p, d, round_up(d, 128), s);
+    } else if (name == "output_process.poseFinal.weight") {
+        if (!shape_is(shape, ndim, {J, d})) return bad();
+        rc = pack(h, h->outp, p, J, d, 0, d, s);
+    } else if (name == "output_process.poseFinal.bias") {
+        if (!shape_is(shape, ndim, {J})) return bad();
+        rc = pack_vec(h, &h->outp.bias, p, J, round_up(J, 128), s);
+    } else if (name == "sequence_pos_encoder.pe") {
+        if (ndim != 3 || shape[1] != 1 || shape[2] != d) return bad();
+        h->pe_rows = (int)shape[0];
+        h->pe = nullptr;
+        rc = pack_vec(h, &h->pe, p, h->pe_rows * d, h->pe_rows * d, s);
+    } else if ((name == "rope.cos" || name == "rope.sin") && h->cfg.arch == GDX_ARCH_MDM) {
+        const int half = d / h->cfg.cl_head / 2;
+        if (ndim != 2 || shape[1] != half) return bad();
+        float** dst = name == "rope.cos" ? &h->rope_cos : &h->rope_sin;
+        *dst = nullptr;
+        h->rope_rows = (int)shape[0];
+        rc = pack_vec(h, dst, p, h->rope_rows * half, h->rope_rows * half, s);
+    } else if (name.rfind("seqTransEncoder.layers.", 0) == 0) {
+        const size_t p0 = strlen("seqTransEncoder.layers.");
+        const size_t dot = name.find('.', p0);
+        if (dot == std::string::npos) return fail("gdx_set_weight: unexpected key " + name);
+        const int l = atoi(name.substr(p0, dot - p0).c_str());
+        if (l < 0 || l >= h->L) return fail("gdx_set_weight: unexpected key " + name);
+        Layer& ly = h->layers[l];
+        const std::string sub = name.substr(dot + 1);
+        if (sub == "self_attn.in_proj_weight") {
+            if (!shape_is(shape, ndim, {3 * d, d})) return bad();
+            rc = pack(h, ly.qkv, p, 3 * d, d, 0, d, s);
+        } else if (sub == "self_attn.in_proj_bias") {
+            if (!shape_is(shape, ndim, {3 * d})) return bad();
+            rc = pack_vec(h, &ly.qkv.bias, p, 3 * d, round_up(3 * d, 128), s);
+        } else if (sub == "self_attn.out_proj.weight") {
+            if (!shape_is(shape, ndim, {d, d})) return bad();
+            rc = pack(h, ly.out, p, d, d, 0, d, s);
+        } else if (sub == "self_attn.out_proj.bias") {
+            if (!shape_is(shape, ndim, {d})) return bad();
+            rc = pack_vec(h, &ly.out.bias, p, d, round_up(d, 128), s);
+        } else if (sub == "linear1.weight") {
+            if (!shape_is(shape, ndim, {ff, d})) return bad();
+            rc = pack(h, ly.ff1, p, ff, d, 0, d, s);
+        } else if (sub == "linear1.bias") {
+            if (!shape_is(shape, ndim, {ff})) return bad();
+            rc = pack_vec(h, &ly.ff1.bias, p, ff, round_up(ff, 128), s);
+        } else if (sub == "linear2.weight") {
+            if (!shape_is(shape, ndim, {d, ff})) return bad();
+            rc = pack(h, ly.ff2, p, d, ff, 0, ff, s);
+        } else if (sub == "linear2.bias") {
+            if (!shape_is(shape, ndim, {d})) return bad();
+            rc = pack_vec(h, &ly.ff2.bias, p, d, round_up(d, 128), s);
+        } else if (sub == "norm1.weight" || sub == "norm1.bias" || sub == "norm2.weight" || sub == "norm2.bias") {
+            if (!shape_is(shape, ndim, {d})) return bad();
+            float** dst = sub == "norm1.weight" ? &ly.g1 : sub == "norm1.bias" ? &ly.b1 : sub == "norm2.weight" ? &ly.g2 : &ly.b2;
+            rc = pack_vec(h, dst, p, d, d, s);
+        } else {
+            return fail("gdx_set_weight: unexpected key " + name);
+        }
+    } else {
+        return fail("gdx_set_weight: unexpected key " + name);   // load_model_wo_clip asserts no unexpected keys
+    }
+    if (rc) return rc;
+    h->have.insert(name);
+    h->cond_set = false;
+    return 0;
+}
+
+extern "C" int gdx_weights_ready(gdx_handle_t h) {
+    if (!h) return fail("gdx_weights_ready: null handle");
+    std::string missing;
+    for (const auto& n : h->required)
+        if (!h->have.count(n)) missing += (missing.empty() ? "" : ", ") + n;
+    if (!missing.empty()) return fail("missing weights: " + missing);
+    return 0;
+}
+
+extern "C" int gdx_prepare(gdx_handle_t h, int32_t batch, int32_t frames) {
+    if (!h) return fail("gdx_prepare: null handle");
+    if (batch <= 0 || frames <= 0) return fail("gdx_prepare: batch and frames must be positive");
+    if (h->cfg.arch == GDX_ARCH_MDM && frames % h->cfg.window)
+        return fail("gdx_prepare: sequence length must be divisible by window size for local attention");
+    if (h->pe && frames + 1 > h->pe_rows) return fail("gdx_prepare: frames exceed positional table");
+    if (h->cfg.arch == GDX_ARCH_MDM && h->rope_cos && frames + 1 > h->rope_rows)
+        return fail("gdx_prepare: frames exceed rotary table");
+    if (h->B == batch && h->T == frames) return 0;
+    free_pool(h->ws_allocs);
+    h->taps.clear();
+    h->temb_table = nullptr; h->temb_table_rows = 0; h->tmap_dev = nullptr;
+    h->B = batch; h->T = frames; h->S = frames + 1; h->cond_set = false;
+    const size_t B2 = 2 * (size_t)batch, N = B2 * h->S, d = h->d;
+    auto A = [&](float** p, size_t n) { return dev_alloc(h->ws_allocs, (void**)p, n * sizeof(float)); };
+    if (A(&h->xa, N * d) || A(&h->xb, N * d) || A(&h->qkv, N * 3 * d) || A(&h->ctx, N * d) || A(&h->tmp, N * d) ||
+        A(&h->ffb, N * h->ff) || A(&h->addend, N * d) || A(&h->seed_cat, B2 * d) || A(&h->temb_in, B2 * d) ||
+        A(&h->temb_h, B2 * d) || A(&h->temb, B2 * d) || A(&h->coa, B2 * d) || A(&h->c2, B2 * d) ||
+        A(&h->x0, B2 * h->J * (size_t)frames))
+        return -1;
+    if (h->cfg.arch == GDX_ARCH_MDM && (A(&h->emb_pose, B2 * frames * d) || A(&h->xseq, B2 * frames * d))) return -1;
+    if (h->keep_taps) {
+        h->taps.resize(h->L + 1);
+        for (auto& t : h->taps)
+            if (A(&t, N * d)) return -1;
+    }
+    return 0;
+}
+
+extern "C" int gdx_set_keep_taps(gdx_handle_t h, int32_t keep) {
+    if (!h) return fail("gdx_set_keep_taps: null handle");
+    if (h->keep_taps != (keep != 0)) {
+        h->keep_taps = keep != 0;
+        const int B = h->B, T = h->T;
+        if (B) {
+            h->B = 0;
+            return gdx_prepare(h, B, T);
+        }
+    }
+    return 0;
+}
+
+extern "C" int gdx_get_tap(gdx_handle_t h, int32_t which, float* out, int64_t count, void* stream) {
+    if (!h || !out) return fail("gdx_get_tap: null argument");
+    if (!h->keep_taps || which < 0 || which > h->L || h->taps.empty()) return fail("gdx_get_tap: taps not kept");
+    const int64_t maxc = 2LL * h->B * h->S * h->d;
+    if (count > maxc) return fail("gdx_get_tap: count too large");
+    HIPCHK(hipMemcpyAsync(out, h->taps[which], count * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return 0;
+}
+
+extern "C" int gdx_set_condition(gdx_handle_t h, const float* seed, const float* mfcc, void* stream) {
+    if (!h || !seed || !mfcc) return fail("gdx_set_condition: null argument");
+    if (gdx_weights_ready(h)) return -1;
+    if (!h->B) return fail("gdx_set_condition: call gdx_prepare first");
+    hipStream_t s = (hipStream_t)stream;
+    const int B = h->B, T = h->T, S = h->S, d = h->d;
+    // cond rows 0..B-1: Linear(flat seed); uncond rows B..2B-1: Linear(0) = bias   (model/mdm.py:125-127,242-250)
+    HIPCHK(launch_small_linear(seed, h->J * h->cfg.seed_poses, h->seed.w, h->seed.kpad, h->seed.bias, h->seed_cat, d, B,
+                               d, h->J * h->cfg.seed_poses, 0, s));
+    for (int b = 0; b < B; ++b)
+        HIPCHK(hipMemcpyAsync(h->seed_cat + (size_t)(B + b) * d, h->seed.bias, sizeof(float) * d,
+                              hipMemcpyDeviceToDevice, s));
+    if (h->cfg.arch == GDX_ARCH_MDM_OLD) {
+        // addend[b, t+1, :] = W_in[:, J:] mfcc[b,:,t] + b_in + pe[t+1]      (model/mdm_old.py:104-112)
+        HIPCHK(launch_mfcc_project(mfcc, h->in_mfcc.w, h->in_mfcc.kpad, h->in_x.bias, h->pe, h->addend, 2 * B, B,
+                                   h->cfg.mfcc_dim, T, d, S, 1, s));
+    } else {
+        // audio_term[b*T+t, :] = W_proj[:, d:d+26] mfcc[b,:,t] + b_proj     (model/mdm.py:151-169)
+        HIPCHK(launch_mfcc_project(mfcc, h->proj_audio.w, h->proj_audio.kpad, h->proj_pose.bias, nullptr, h->addend,
+                                   2 * B, B, h->cfg.mfcc_dim, T, d, T, 0, s));
+    }
+    h->cond_set = true;
+    return 0;
+}
+
+static int gemm(int am, int bm, int om, int ep, const GemmParams& p, hipStream_t s) {
+    hipError_t e = launch_gemm(am, bm, om, ep, p, s);
+    if (e != hipSuccess) return fail(std::string("launch_gemm: ") + hipGetErrorString(e));
+    return 0;
+}
+
+// The per-step kernel sequence.  temb: [*, d] rows (row stride tstride, 0 = shared by the batch).
+// Writes x0 for Beff samples into x0_out ([Beff, J, T]).
+static int forward_core(gdx_model* h, const float* x, const float* temb, int tstride, int mode, float* x0_out,
+                        hipStream_t s) {
+    const int B = h->B, T = h->T, S = h->S, d = h->d, J = h->J;
+    const int Beff = mode == GDX_CFG ? 2 * B : B;
+    const float* seed_emb = mode == GDX_UNCOND ? h->seed_cat + (size_t)B * d : h->seed_cat;
+    const int N = Beff * S;
+    GemmParams p;
+    if (h->cfg.arch == GDX_ARCH_MDM_OLD) {
+        HIPCHK(launch_token0(temb, tstride, seed_emb, h->pe, h->xa, nullptr, Beff, B, S, d, s));
+        p = GemmParams{x, 0, h->in_x.w, h->in_x.kpad, nullptr, h->addend, d, nullptr, 0, h->xa, d, Beff * T, d, J, T, B};
+        if (gemm(A_POSE, B_WEIGHT, OUT_TOKROWS, EPI_RES, p, s)) return -1;
+    } else {
+        HIPCHK(launch_token0(temb, tstride, seed_emb, nullptr, h->xa, h->coa, Beff, B, S, d, s));
+        p = GemmParams{x, 0, h->in_x.w, h->in_x.kpad, h->in_x.bias, nullptr, 0, nullptr, 0, h->emb_pose, d, Beff * T, d, J, T, B};
+        if (gemm(A_POSE, B_WEIGHT, OUT_ROWS, EPI_BIAS, p, s)) return -1;
+        HIPCHK(launch_small_linear(h->coa, d, h->proj_coa.w, h->proj_coa.kpad, nullptr, h->c2, d, Beff, d, d, 0, s));
+        p = GemmParams{h->emb_pose, d, h->proj_pose.w, h->proj_pose.kpad, nullptr, h->addend, d, h->c2, d, h->xseq, d, Beff * T, d, d, T, B};
+        if (gemm(A_ROWS, B_WEIGHT, OUT_ROWS, EPI_RES_VEC, p, s)) return -1;
+        HIPCHK(launch_local_attention(h->xseq, h->rope_cos, h->rope_sin, h->xa, Beff, T, d, h->cfg.cl_head,
+                                      h->cfg.window, s));
+    }
+    if (h->keep_taps)
+        HIPCHK(hipMemcpyAsync(h->taps[0], h->xa, sizeof(float) * (size_t)N * d, hipMemcpyDeviceToDevice, s));
+    for (int l = 0; l < h->L; ++l) {
+        const Layer& ly = h->layers[l];
+        p = GemmParams{h->xa, d, ly.qkv.w, ly.qkv.kpad, ly.qkv.bias, nullptr, 0, nullptr, 0, h->qkv, 3 * d, N, 3 * d, d, T, B};
+        if (gemm(A_ROWS, B_WEIGHT, OUT_ROWS, EPI_BIAS, p, s)) return -1;
+        HIPCHK(launch_attention(h->qkv, h->ctx, Beff, S, h->H, d, s));
+        p = GemmParams{h->ctx, d, ly.out.w, ly.out.kpad, ly.out.bias, h->xa, d, nullptr, 0, h->tmp, d, N, d, d, T, B};
+        if (gemm(A_ROWS, B_WEIGHT, OUT_ROWS, EPI_RES, p, s)) return -1;
+        HIPCHK(launch_layernorm(h->tmp, ly.g1, ly.b1, h->xb, N, d, s));
+        p = GemmParams{h->xb, d, ly.ff1.w, ly.ff1.kpad, ly.ff1.bias, nullptr, 0, nullptr, 0, h->ffb, h->ff, N, h->ff, d, T, B};
+        if (gemm(A_ROWS, B_WEIGHT, OUT_ROWS, EPI_GELU, p, s)) return -1;
+        p = GemmParams{h->ffb, h->ff, ly.ff2.w, ly.ff2.kpad, ly.ff2.bias, h->xb, d, nullptr, 0, h->tmp, d, N, d, h->ff, T, B};
+        if (gemm(A_ROWS, B_WEIGHT, OUT_ROWS, EPI_RES, p, s)) return -1;
+        HIPCHK(launch_layernorm(h->tmp, ly.g2, ly.b2, h->xa, N, d, s));
+        if (h->keep_taps)
+            HIPCHK(hipMemcpyAsync(h->taps[l + 1], h->xa, sizeof(float) * (size_t)N * d, hipMemcpyDeviceToDevice, s));
+    }
+    // OutputProcess, swapped: x0[b, j, t] = sum_k W_out[j][k] * h[b, t+1, k] + b_out[j]   (model/mdm.py:372-380)
+    p = GemmParams{h->outp.w, h->outp.kpad, h->xa, d, h->outp.bias, nullptr, 0, nullptr, 0, x0_out, 0, J, Beff * T, d, T, B};
+    if (gemm(A_ROWS, B_TOKENS, OUT_POSE, EPI_BIAS, p, s)) return -1;
+    return 0;
+}
+
+static int check_ready(gdx_model* h, const char* who) {
+    if (!h) return fail(std::string(who) + ": null handle");
+    if (!h->B) return fail(std::string(who) + ": call gdx_prepare first");
+    if (!h->cond_set) return fail(std::string(who) + ": call gdx_set_condition first");
+    return 0;
+}
+
+// timestep embedding rows for idx[M] (model/mdm.py:296-310): pe gather -> Linear -> SiLU -> Linear
+static int time_embed(gdx_model* h, const int64_t* idx, int M, float* gathered, float* hidden, float* out,
+                      hipStream_t s) {
+    const int d = h->d;
+    HIPCHK(launch_gather_rows(h->pe, idx, gathered, M, d, h->pe_rows, s));
+    HIPCHK(launch_small_linear(gathered, d, h->time0.w, h->time0.kpad, h->time0.bias, hidden, d, M, d, d, 1, s));
+    HIPCHK(launch_small_linear(hidden, d, h->time2.w, h->time2.kpad, h->time2.bias, out, d, M, d, d, 0, s));
+    return 0;
+}
+
+extern "C" int gdx_forward(gdx_handle_t h, const float* x, const int64_t* timesteps, int32_t mode, const float* scale,
+                           float* out, void* stream) {
+    if (check_ready(h, "gdx_forward")) return -1;
+    if (!x || !timesteps || !out) return fail("gdx_forward: null argument");
+    if (mode < GDX_COND || mode > GDX_CFG) return fail("gdx_forward: bad mode");
+    if (mode == GDX_CFG && !scale) return fail("gdx_forward: GDX_CFG needs scale");
+    hipStream_t s = (hipStream_t)stream;
+    if (time_embed(h, timesteps, h->B, h->temb_in, h->temb_h, h->temb, s)) return -1;
+    if (mode != GDX_CFG) return forward_core(h, x, h->temb, h->d, mode, out, s);
+    if (forward_core(h, x, h->temb, h->d, mode, h->x0, s)) return -1;
+    const int64_t per = (int64_t)h->J * h->T;
+    HIPCHK(launch_cfg_blend(h->x0, h->x0 + (size_t)h->B * per, scale, out, h->B, per, s));
+    return 0;
+}
+
+extern "C" int gdx_sample_loop(gdx_handle_t h, const gdx_loop_args_t* a, void* stream) {
+    if (check_ready(h, "gdx_sample_loop")) return -1;
+    if (!a || !a->coef || !a->timestep_map || !a->x) return fail("gdx_sample_loop: null argument");
+    if (a->mode < GDX_COND || a->mode > GDX_CFG) return fail("gdx_sample_loop: bad mode");
+    if (a->mode == GDX_CFG && !a->scale) return fail("gdx_sample_loop: GDX_CFG needs scale");
+    if (a->num_steps <= 0 || a->first_index >= a->num_steps) return fail("gdx_sample_loop: bad step range");
+    if (a->kind == GDX_SAMPLER_DDIM && (a->const_noise || a->n_dump))
+        return fail("gdx_sample_loop: ddim_sample_loop supports neither const_noise nor dump_steps");  // :903-906
+    hipStream_t s = (hipStream_t)stream;
+    const int B = h->B, d = h->d;
+    // timestep-embedding table for every kept step, once per loop (same t for the whole batch:
+    // gaussian_diffusion.py:712), through the respacing map (respace.py:124-129)
+    if (h->temb_table_rows < a->num_steps) {
+        float* t3 = nullptr;
+        if (dev_alloc(h->ws_allocs, (void**)&t3, sizeof(float) * 3 * (size_t)a->num_steps * d)) return -1;
+        if (dev_alloc(h->ws_allocs, (void**)&h->tmap_dev, sizeof(int64_t) * a->num_steps)) return -1;
+        h->temb_table = t3;
+        h->temb_table_rows = a->num_steps;
+    }
+    HIPCHK(hipMemcpyAsync(h->tmap_dev, a->timestep_map, sizeof(int64_t) * a->num_steps, hipMemcpyHostToDevice, s));
+    float* table = h->temb_table;
+    float* scratch0 = table + (size_t)h->temb_table_rows * d;
+    float* scratch1 = scratch0 + (size_t)h->temb_table_rows * d;
+    if (time_embed(h, h->tmap_dev, a->num_steps, scratch0, scratch1, table, s)) return -1;
+
+    const int64_t per = (int64_t)h->J * h->T;
+    int dump_i = 0;
+    for (int k = 0, idx = a->first_index; idx >= 0; --idx, ++k) {
+        if (forward_core(h, a->x, table + (size_t)idx * d, 0, a->mode, h->x0, s)) return -1;
+        gdx_update_args_t u;
+        memset(&u, 0, sizeof(u));
+        u.kind = a->kind; u.batch = B; u.njoints = h->J; u.frames = h->T;
+        u.coef = a->coef; u.t = nullptr; u.step_index = idx;
+        u.x = a->x; u.x0_cond = h->x0;
+        u.x0_uncond = a->mode == GDX_CFG ? h->x0 + (size_t)B * per : nullptr;
+        u.scale = a->scale;
+        u.inpaint_mask = a->inpaint_mask; u.inpaint_motion = a->inpaint_motion;
+        u.noise = a->noise_tape ? a->noise_tape + (size_t)k * (a->const_noise ? 1 : B) * per : nullptr;
+        u.const_noise = a->const_noise;
+        u.philox_seed = a->philox_seed; u.sample_offset = a->sample_offset; u.rng_step = (uint32_t)(k + 1);
+        u.out = a->x; u.pred_xstart = nullptr;
+        if (gdx_sampler_update(&u, stream)) return -1;
+        if (a->dump && dump_i < a->n_dump && a->dump_steps[dump_i] == k) {
+            HIPCHK(hipMemcpyAsync(a->dump + (size_t)dump_i * B * per, a->x, sizeof(float) * B * per,
+                                  hipMemcpyDeviceToDevice, s));
+            ++dump_i;
+        }
+    }
+    return 0;
+}
+
+extern "C" int gdx_forward_flops(gdx_handle_t h, int32_t mode, double* flops) {
+    if (!h || !flops) return fail("gdx_forward_flops: null argument");
+    if (!h->B) return fail("gdx_forward_flops: call gdx_prepare first");
+    // SURVEY.md section 8d
+    const double B = (mode == GDX_CFG ? 2.0 : 1.0) * h->B, T = h->T, S = h->S, d = h->d, J = h->J, ff = h->ff;
+    const double N = B * S, Sp = h->cfg.seed_poses, mf = h->cfg.mfcc_dim;
+    double f = 2 * B * d * d * 2 + 2 * B * J * Sp * d;
+    if (h->cfg.arch == GDX_ARCH_MDM)
+        f += 2 * B * T * J * d + 2 * B * T * (2 * d + mf) * d + 4 * B * T * 2 * h->cfg.window * d;
+    else
+        f += 2 * B * T * (J + mf) * d;
+    f += h->L * (2 * N * d * 3 * d + 4 * B * S * S * d + 2 * N * d * d + 4 * N * d * ff);
+    f += 2 * B * T * d * J;
+    *flops = f;
+    return 0;
+}
+
+extern "C" int gdx_bench_ffn_gemm(gdx_handle_t h, int32_t iters, float* avg_us, void* stream) {
+    if (!h || !avg_us) return fail("gdx_bench_ffn_gemm: null argument");
+    if (!h->B) return fail("gdx_bench_ffn_gemm: call gdx_prepare first");
+    if (gdx_weights_ready(h)) return -1;
+    hipStream_t s = (hipStream_t)stream;
+    const int N = h->B * h->S, d = h->d;
+    const Layer& ly = h->layers[0];
+    GemmParams p{h->xb, d, ly.ff1.w, ly.ff1.kpad, ly.ff1.bias, nullptr, 0, nullptr, 0, h->ffb, h->ff, N, h->ff, d, h->T, h->B};
+    hipEvent_t e0, e1;
+    HIPCHK(hipEventCreate(&e0));
+    HIPCHK(hipEventCreate(&e1));
+    if (gemm(A_ROWS, B_WEIGHT, OUT_ROWS, EPI_GELU, p, s)) return -1;   // warm
+    HIPCHK(hipEventRecord(e0, s));
+    for (int i = 0; i < iters; ++i)
+        if (gemm(A_ROWS, B_WEIGHT, OUT_ROWS, EPI_GELU, p, s)) return -1;
+    HIPCHK(hipEventRecord(e1, s));
+    HIPCHK(hipEventSynchronize(e1));
+    float ms = 0.f;
+    HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+    *avg_us = ms * 1000.0f / (float)iters;
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    return 0;
+}

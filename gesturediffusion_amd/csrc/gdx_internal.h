@@ -1,0 +1,66 @@
+// Internal launcher declarations shared by the libgdx.so translation units (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace gdx {
+
+// ---- GEMM (gemm.hip) ---------------------------------------------------------------------
+// C = A * W^T (+ epilogue).  W is a packed weight [Npad][ldw], K-contiguous, zero padded to
+// multiples of 128 rows / 32 columns, so the weight operand never needs a bounds check.
+enum AMode { A_ROWS = 0,      // A[m][k] = A[m*lda + k]
+             A_POSE = 1 };    // A[m][k] = x[(b*K + k)*T + t],  m = b*T + t   (pose tensor, k-major)
+enum BMode { B_WEIGHT = 0,    // second operand is the padded weight
+             B_TOKENS = 1 };  // second operand rows are tokens: row(n) = n + n/T + 1 (skip token 0), n < N
+enum OutMode { OUT_ROWS = 0,     // C[m*ldc + n]
+               OUT_TOKROWS = 1,  // C[(m + m/T + 1)*ldc + n]   (frames into [B, T+1, d], token 0 skipped)
+               OUT_POSE = 2 };   // C[((n/T)*M + m)*T + n%T]    (swapped GEMM -> pose tensor [B, M=J, 1, T])
+enum Epi { EPI_BIAS = 0,      // + bias[n]      (bias[m] for OUT_POSE)
+           EPI_GELU = 1,      // gelu_erf(. + bias[n])
+           EPI_RES = 2,       // + bias[n] + R[row_out*ldr + n]
+           EPI_RES_VEC = 3 }; // + R[row_out*ldr + n] + V[(m/T)*ldv + n]
+
+struct GemmParams {
+    const float* A; int lda;
+    const float* W; int ldw;
+    const float* bias;
+    const float* R; int ldr;
+    const float* V; int ldv;
+    float* C; int ldc;
+    int M, N, K;   // K: multiple of 32 for A_ROWS; true K for A_POSE (guarded)
+    int T;         // frames per sample, for the row maps
+    int Bmod;      // A_POSE: source sample = (m / T) % Bmod (CFG runs the same x through both passes)
+};
+
+hipError_t gemm_init();   // raises the dynamic-LDS limit of every instantiation
+hipError_t launch_gemm(int amode, int bmode, int omode, int epi, const GemmParams& p, hipStream_t s);
+
+// ---- attention (attention.hip) -----------------------------------------------------------
+// qkv [B*S][3d] (q | k | v, heads contiguous inside each), ctx [B*S][d]
+hipError_t launch_attention(const float* qkv, float* ctx, int B, int S, int H, int d, hipStream_t s);
+
+// ---- misc (misc.hip) ---------------------------------------------------------------------
+hipError_t launch_layernorm(const float* x, const float* gamma, const float* beta, float* out,
+                            int rows, int d, hipStream_t s);
+// out[m][n] = act(sum_k A[m*lda+k] * W[n*ldw+k] + bias[n]);  act: 0 none, 1 SiLU.  K arbitrary.
+hipError_t launch_small_linear(const float* A, int lda, const float* W, int ldw, const float* bias,
+                               float* out, int ldo, int M, int N, int K, int act, hipStream_t s);
+// out[m][:] = table[idx[m]][:]   (timestep -> sinusoidal row gather)
+hipError_t launch_gather_rows(const float* table, const int64_t* idx, float* out, int M, int d, int max_rows,
+                              hipStream_t s);
+// out[(b*rps + t + off)*d + n] = sum_c mfcc[((b%Bmod)*C + c)*T + t] * W[n*ldw + c] + bias[n] (+ pe[(t+1)*d + n] if pe)
+hipError_t launch_mfcc_project(const float* mfcc, const float* W, int ldw, const float* bias, const float* pe,
+                               float* out, int B, int Bmod, int C, int T, int d, int rps, int off, hipStream_t s);
+// token 0 of the encoder input: enc[b*S*d + n] = temb[(b%Bmod)*tstride + n] + seed[b*d + n] (+ pe0[n]);
+// also writes coa[b*d+n] (same value without pe0) when coa != nullptr.
+hipError_t launch_token0(const float* temb, int tstride, const float* seed_emb, const float* pe0,
+                         float* enc, float* coa, int B, int Bmod, int S, int d, hipStream_t s);
+// V2 front end: RoPE -> causal local attention (window, look back one window) -> RoPE at pos+1,
+// written into enc[b][t+1][:].   xseq [B*T][d];  cos/sin tables [>=T+1][e/2], e = d/heads.
+hipError_t launch_local_attention(const float* xseq, const float* cosT, const float* sinT, float* enc,
+                                  int B, int T, int d, int heads, int window, hipStream_t s);
+// out = u + scale[b]*(c - u)
+hipError_t launch_cfg_blend(const float* c, const float* u, const float* scale, float* out, int B,
+                            int64_t per_sample, hipStream_t s);
+
+}  // namespace gdx

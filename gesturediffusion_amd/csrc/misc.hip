@@ -1,0 +1,298 @@
+// HBM/latency-bound pieces of the denoiser step: LayerNorm, the small per-sample linears
+// (timestep / seed embedding), the MFCC projection hoisted out of the loop, the conditioning
+// token, the fused V2 front end (RoPE -> causal local attention -> RoPE) and the CFG blend.
+#include "gdx_internal.h"
+
+namespace gdx {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// LayerNorm over the last dim (post-norm encoder: model/mdm.py:90-96 -> norm1/norm2, eps 1e-5,
+// biased variance).  The residual add is fused into the producing GEMM's epilogue; one wave per
+// row, the row lives in registers, two-pass mean/variance, wave shuffles for the reduce.
+// HBM-bound: 2 * rows * d * 4 bytes.
+template <int VPL>   // float4 per lane: d = 256 * VPL
+__global__ __launch_bounds__(256) void layernorm_vec_kernel(const float* __restrict__ x, const float* __restrict__ g,
+                                                             const float* __restrict__ bta, float* __restrict__ out,
+                                                             int rows, int d) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    const f32x4* xp = reinterpret_cast<const f32x4*>(x + (long)row * d);
+    f32x4 v[VPL];
+    float s = 0.0f;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+        v[i] = xp[lane + 64 * i];
+        s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+    }
+    const float mean = wave_sum(s) / (float)d;
+    float q = 0.0f;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float c = v[i][e] - mean;
+            q += c * c;
+        }
+    const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)d + 1e-5f);
+    f32x4* op = reinterpret_cast<f32x4*>(out + (long)row * d);
+    const f32x4* gp = reinterpret_cast<const f32x4*>(g);
+    const f32x4* bp = reinterpret_cast<const f32x4*>(bta);
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+        const f32x4 gg = gp[lane + 64 * i], bb = bp[lane + 64 * i];
+        f32x4 r;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) r[e] = (v[i][e] - mean) * rstd * gg[e] + bb[e];
+        op[lane + 64 * i] = r;
+    }
+}
+
+// generic d (multiple of 32, <= 2048): scalar lane-strided loads
+__global__ __launch_bounds__(256) void layernorm_gen_kernel(const float* __restrict__ x, const float* __restrict__ g,
+                                                             const float* __restrict__ bta, float* __restrict__ out,
+                                                             int rows, int d) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    const float* xp = x + (long)row * d;
+    float s = 0.0f;
+    for (int e = lane; e < d; e += 64) s += xp[e];
+    const float mean = wave_sum(s) / (float)d;
+    float q = 0.0f;
+    for (int e = lane; e < d; e += 64) {
+        const float c = xp[e] - mean;
+        q += c * c;
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)d + 1e-5f);
+    for (int e = lane; e < d; e += 64) out[(long)row * d + e] = (xp[e] - mean) * rstd * g[e] + bta[e];
+}
+
+hipError_t launch_layernorm(const float* x, const float* gamma, const float* beta, float* out, int rows, int d,
+                            hipStream_t s) {
+    const dim3 grid((rows + 3) / 4), block(256);
+    if (d == 512)
+        hipLaunchKernelGGL(layernorm_vec_kernel<2>, grid, block, 0, s, x, gamma, beta, out, rows, d);
+    else if (d == 1024)
+        hipLaunchKernelGGL(layernorm_vec_kernel<4>, grid, block, 0, s, x, gamma, beta, out, rows, d);
+    else if (d == 256)
+        hipLaunchKernelGGL(layernorm_vec_kernel<1>, grid, block, 0, s, x, gamma, beta, out, rows, d);
+    else
+        hipLaunchKernelGGL(layernorm_gen_kernel, grid, block, 0, s, x, gamma, beta, out, rows, d);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// Small-M linear (timestep MLP model/mdm.py:296-310, seed-pose encoder :382-392, the per-sample
+// coarse-vector slice of project_to_lat :154-169).  M is the batch (<= a few hundred rows): pure
+// latency, one wave per output element, lane-strided coalesced K loop, shuffle reduce.
+__global__ __launch_bounds__(256) void small_linear_kernel(const float* __restrict__ A, int lda,
+                                                            const float* __restrict__ W, int ldw,
+                                                            const float* __restrict__ bias, float* __restrict__ out,
+                                                            int ldo, int M, int N, int K, int act) {
+    const int n = blockIdx.x;
+    const int m = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (m >= M) return;
+    const float* a = A + (long)m * lda;
+    const float* w = W + (long)n * ldw;
+    float s = 0.0f;
+    for (int k = lane; k < K; k += 64) s = fmaf(a[k], w[k], s);
+    s = wave_sum(s);
+    if (lane == 0) {
+        if (bias) s += bias[n];
+        if (act == 1) s = s / (1.0f + expf(-s));   // SiLU
+        out[(long)m * ldo + n] = s;
+    }
+}
+
+hipError_t launch_small_linear(const float* A, int lda, const float* W, int ldw, const float* bias, float* out,
+                               int ldo, int M, int N, int K, int act, hipStream_t s) {
+    const dim3 grid(N, (M + 3) / 4), block(256);
+    hipLaunchKernelGGL(small_linear_kernel, grid, block, 0, s, A, lda, W, ldw, bias, out, ldo, M, N, K, act);
+    return hipGetLastError();
+}
+
+__global__ void gather_rows_kernel(const float* __restrict__ table, const int64_t* __restrict__ idx,
+                                   float* __restrict__ out, int M, int d, int max_rows) {
+    const int m = blockIdx.x;
+    long r = idx[m];
+    r = r < 0 ? 0 : (r >= max_rows ? max_rows - 1 : r);
+    for (int e = threadIdx.x; e < d; e += blockDim.x) out[(long)m * d + e] = table[r * d + e];
+}
+
+hipError_t launch_gather_rows(const float* table, const int64_t* idx, float* out, int M, int d, int max_rows,
+                              hipStream_t s) {
+    hipLaunchKernelGGL(gather_rows_kernel, dim3(M), dim3(256), 0, s, table, idx, out, M, d, max_rows);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// Step-invariant MFCC slice of the input linear (V1: model/mdm_old.py:104-108 concatenates the 26
+// MFCC channels onto the pose channels before InputProcess; V2: model/mdm.py:151-169 feeds them to
+// project_to_lat).  Computed once per conditioning, not once per step:
+//   out[b,t,n] = sum_c mfcc[b,c,t] * W[n][c] + bias[n] (+ pe[t+1][n])
+__global__ __launch_bounds__(256) void mfcc_project_kernel(const float* __restrict__ mfcc, const float* __restrict__ W,
+                                                           int ldw, const float* __restrict__ bias,
+                                                           const float* __restrict__ pe, float* __restrict__ out,
+                                                           int B, int Bmod, int C, int T, int d, int rps, int off) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long)B * T * d) return;
+    const int n = i % d;
+    const long bt = i / d;
+    const int t = bt % T, b = bt / T;
+    const int bs = b % Bmod;
+    float s = 0.0f;
+    for (int c = 0; c < C; ++c) s = fmaf(mfcc[((long)bs * C + c) * T + t], W[(long)n * ldw + c], s);
+    s += bias[n];
+    if (pe) s += pe[(long)(t + 1) * d + n];
+    out[((long)b * rps + t + off) * d + n] = s;
+}
+
+hipError_t launch_mfcc_project(const float* mfcc, const float* W, int ldw, const float* bias, const float* pe,
+                               float* out, int B, int Bmod, int C, int T, int d, int rps, int off, hipStream_t s) {
+    const long n = (long)B * T * d;
+    hipLaunchKernelGGL(mfcc_project_kernel, dim3((n + 255) / 256), dim3(256), 0, s, mfcc, W, ldw, bias, pe, out, B,
+                       Bmod, C, T, d, rps, off);
+    return hipGetLastError();
+}
+
+// conditioning token (model/mdm_old.py:94-111: emb_t + emb_seed, then + pe[0]; model/mdm.py:154-160,197)
+__global__ void token0_kernel(const float* __restrict__ temb, int tstride, const float* __restrict__ seed_emb,
+                              const float* __restrict__ pe0, float* __restrict__ enc, float* __restrict__ coa, int B,
+                              int Bmod, int S, int d) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * d) return;
+    const int b = i / d, n = i % d;
+    float v = temb[(long)(b % Bmod) * tstride + n] + seed_emb[i];
+    if (coa) coa[i] = v;
+    if (pe0) v += pe0[n];
+    enc[(long)b * S * d + n] = v;
+}
+
+hipError_t launch_token0(const float* temb, int tstride, const float* seed_emb, const float* pe0, float* enc,
+                         float* coa, int B, int Bmod, int S, int d, hipStream_t s) {
+    hipLaunchKernelGGL(token0_kernel, dim3((B * d + 255) / 256), dim3(256), 0, s, temb, tstride, seed_emb, pe0, enc,
+                       coa, B, Bmod, S, d);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// V2 front end, one wave per (sample, local head, window):
+//   rotary embedding (NeoX half-split, model/local_attention.py:43-62) of the <= 2*window rows it needs,
+//   causal windowed attention with q = k = v (model/local_attention.py:92-172 as configured at
+//   model/mdm.py:72-80: look back one window, scale e^-0.5, padded look-back keys masked),
+//   second rotary at position t+1 (model/mdm.py:197-213; token 0 sits at position 0 where the
+//   rotation is the identity), result written straight into the encoder input [B, T+1, d].
+// All intermediates live in LDS; nothing but xseq is read and enc_in written.
+__global__ __launch_bounds__(64) void local_attention_kernel(const float* __restrict__ xseq,
+                                                             const float* __restrict__ cosT,
+                                                             const float* __restrict__ sinT, float* __restrict__ enc,
+                                                             int T, int d, int heads, int window) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int e = d / heads, half = e >> 1;
+    const int nwin = T / window;
+    const int w = blockIdx.x % nwin;
+    const int head = (blockIdx.x / nwin) % heads;
+    const int b = blockIdx.x / (nwin * heads);
+    const int lane = threadIdx.x;
+    const int k0 = w == 0 ? 0 : (w - 1) * window;
+    const int q0 = w * window;
+    const int nkeys = q0 + window - k0;          // window or 2*window
+    const int es = e + 1;                        // padded row stride
+    float* xr = sm;                              // [nkeys][es]   rotated rows
+    float* sc = xr + 2 * window * es;            // [window][2*window] scores / probabilities
+    float* ob = sc + window * 2 * window;        // [window][es]  attention output
+
+    const float* xb = xseq + ((long)b * T) * d + head * e;
+    for (int i = lane; i < nkeys * e; i += 64) {
+        const int r = i / e, c = i % e;
+        const int pos = k0 + r;
+        const float* row = xb + (long)pos * d;
+        const float x = row[c];
+        const float rot = c < half ? -row[c + half] : row[c - half];
+        const int f = c < half ? c : c - half;
+        xr[r * es + c] = x * cosT[pos * half + f] + rot * sinT[pos * half + f];
+    }
+    __syncthreads();
+    const float scale = 1.0f / sqrtf((float)e);
+    for (int p = lane; p < window * nkeys; p += 64) {
+        const int qi = p / nkeys, kj = p % nkeys;
+        const float* qr = xr + (q0 - k0 + qi) * es;
+        const float* kr = xr + kj * es;
+        float s = 0.0f;
+        for (int c = 0; c < e; ++c) s = fmaf(qr[c], kr[c], s);
+        s *= scale;
+        if (k0 + kj > q0 + qi) s = -INFINITY;    // causal
+        sc[qi * 2 * window + kj] = s;
+    }
+    __syncthreads();
+    if (lane < window) {
+        float* r = sc + lane * 2 * window;
+        float mx = -INFINITY;
+        for (int k = 0; k < nkeys; ++k) mx = fmaxf(mx, r[k]);
+        float sum = 0.0f;
+        for (int k = 0; k < nkeys; ++k) {
+            r[k] = expf(r[k] - mx);
+            sum += r[k];
+        }
+        const float inv = 1.0f / sum;
+        for (int k = 0; k < nkeys; ++k) r[k] *= inv;
+    }
+    __syncthreads();
+    for (int i = lane; i < window * e; i += 64) {
+        const int qi = i / e, c = i % e;
+        const float* pr = sc + qi * 2 * window;
+        float s = 0.0f;
+        for (int k = 0; k < nkeys; ++k) s = fmaf(pr[k], xr[k * es + c], s);
+        ob[qi * es + c] = s;
+    }
+    __syncthreads();
+    float* eb = enc + ((long)b * (T + 1)) * d + head * e;
+    for (int i = lane; i < window * e; i += 64) {
+        const int qi = i / e, c = i % e;
+        const int pos = q0 + qi + 1;             // position in the [token | frames] sequence
+        const float x = ob[qi * es + c];
+        const float rot = c < half ? -ob[qi * es + c + half] : ob[qi * es + c - half];
+        const int f = c < half ? c : c - half;
+        eb[(long)pos * d + c] = x * cosT[pos * half + f] + rot * sinT[pos * half + f];
+    }
+}
+
+hipError_t launch_local_attention(const float* xseq, const float* cosT, const float* sinT, float* enc, int B, int T,
+                                  int d, int heads, int window, hipStream_t s) {
+    const int e = d / heads;
+    const size_t lds = (size_t)(2 * window * (e + 1) + window * 2 * window + window * (e + 1)) * sizeof(float);
+    const dim3 grid(B * heads * (T / window)), block(64);
+    hipLaunchKernelGGL(local_attention_kernel, grid, block, lds, s, xseq, cosT, sinT, enc, T, d, heads, window);
+    return hipGetLastError();
+}
+
+// classifier-free guidance blend (model/cfg_sampler.py:28), op order as the reference
+__global__ void cfg_blend_kernel(const float* __restrict__ c, const float* __restrict__ u,
+                                 const float* __restrict__ scale, float* __restrict__ out, long per_sample,
+                                 long total) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const float sc = scale[i / per_sample];
+    const float diff = __fsub_rn(c[i], u[i]);
+    out[i] = __fadd_rn(u[i], __fmul_rn(sc, diff));
+}
+
+hipError_t launch_cfg_blend(const float* c, const float* u, const float* scale, float* out, int B, int64_t per_sample,
+                            hipStream_t s) {
+    const long total = (long)B * per_sample;
+    hipLaunchKernelGGL(cfg_blend_kernel, dim3((total + 255) / 256), dim3(256), 0, s, c, u, scale, out,
+                       (long)per_sample, total);
+    return hipGetLastError();
+}
+
+}  // namespace gdx

@@ -1,0 +1,402 @@
+"""Gaussian diffusion *sampling* process: drop-in for the hot subset of reference
+`diffusion/gaussian_diffusion.py` (schedule :20-64, tables :120-199, q_sample :233-251,
+p_mean_variance :277-388, p_sample :496-548, p_sample_loop{,_progressive} :598-730,
+ddim_sample :732-782, ddim_sample_loop{,_progressive} :879-993).
+
+Host side only builds the fp64 schedule tables (numpy, like the reference) and the per-step fp32
+coefficient rows; every per-element operation runs in libgdx.so:
+
+  * `gdx_forward`         the denoiser (through the model callable protocol `model(x, ts, **kw)`)
+  * `gdx_sampler_update`  CFG blend + inpainting + posterior mean / DDIM step + noise, one pass
+  * `gdx_sample_loop`     the whole loop enqueued from C++ with in-kernel Philox noise
+
+Supported configuration = the one the reference hard-codes (`utils/model_util.py:37-72`):
+START_X mean, FIXED_SMALL / FIXED_LARGE variance.  Training losses, PLMS, cond_fn guidance and
+learned variances are outside the hot path and raise NotImplementedError.
+
+RNG.  `rng="torch"` (default) draws x_T with `torch.randn` and one `torch.randn_like` per step
+from torch's generator on the sample's device, in the reference's order, so a run is
+reproducible against the reference on the same device and seed.  `rng="philox"` uses the fused
+loop with counter-based noise keyed by (seed, global sample index, step): results do not depend
+on how a batch is sharded over GPUs.  `noise_tape=` replays recorded noise (parity tests).
+"""
+import enum
+import math
+
+import numpy as np
+import torch as th
+
+from .. import engine as E
+from ..engine import GDX_CFG, GDX_COND, GDX_UNCOND
+from .._lib import GDX_SAMPLER_DDIM, GDX_SAMPLER_P
+
+
+def get_named_beta_schedule(schedule_name, num_diffusion_timesteps, scale_betas=1.0):
+    if schedule_name == "linear":
+        scale = scale_betas * 1000 / num_diffusion_timesteps
+        return np.linspace(scale * 0.0001, scale * 0.02, num_diffusion_timesteps, dtype=np.float64)
+    if schedule_name == "cosine":
+        return betas_for_alpha_bar(num_diffusion_timesteps,
+                                   lambda t: math.cos((t + 0.008) / 1.008 * math.pi / 2) ** 2)
+    raise NotImplementedError(f"unknown beta schedule: {schedule_name}")
+
+
+def betas_for_alpha_bar(num_diffusion_timesteps, alpha_bar, max_beta=0.999):
+    betas = []
+    for i in range(num_diffusion_timesteps):
+        t1 = i / num_diffusion_timesteps
+        t2 = (i + 1) / num_diffusion_timesteps
+        betas.append(min(1 - alpha_bar(t2) / alpha_bar(t1), max_beta))
+    return np.array(betas)
+
+
+class ModelMeanType(enum.Enum):
+    PREVIOUS_X = enum.auto()
+    START_X = enum.auto()
+    EPSILON = enum.auto()
+
+
+class ModelVarType(enum.Enum):
+    LEARNED = enum.auto()
+    FIXED_SMALL = enum.auto()
+    FIXED_LARGE = enum.auto()
+    LEARNED_RANGE = enum.auto()
+
+
+class LossType(enum.Enum):
+    MSE = enum.auto()
+    RESCALED_MSE = enum.auto()
+    KL = enum.auto()
+    RESCALED_KL = enum.auto()
+
+    def is_vb(self):
+        return self == LossType.KL or self == LossType.RESCALED_KL
+
+
+def _is_native(model):
+    from ..model.cfg_sampler import ClassifierFreeSampleModel
+    from ..model.mdm import _NativeDenoiser
+    return isinstance(model, (_NativeDenoiser, ClassifierFreeSampleModel))
+
+
+class GaussianDiffusion:
+    def __init__(self, *, betas, model_mean_type, model_var_type, loss_type, rescale_timesteps=False,
+                 lambda_rcxyz=0.0, lambda_vel=0.0, lambda_pose=1.0, lambda_orient=1.0, lambda_loc=1.0,
+                 data_rep="rot6d", lambda_root_vel=0.0, lambda_vel_rcxyz=0.0, lambda_fc=0.0):
+        self.model_mean_type = model_mean_type
+        self.model_var_type = model_var_type
+        self.loss_type = loss_type
+        self.rescale_timesteps = rescale_timesteps
+        self.data_rep = data_rep
+        if data_rep != "rot_vel" and lambda_pose != 1.0:
+            raise ValueError("lambda_pose is relevant only when training on velocities!")
+        self.lambda_pose, self.lambda_orient, self.lambda_loc = lambda_pose, lambda_orient, lambda_loc
+        self.lambda_rcxyz, self.lambda_vel, self.lambda_root_vel = lambda_rcxyz, lambda_vel, lambda_root_vel
+        self.lambda_vel_rcxyz, self.lambda_fc = lambda_vel_rcxyz, lambda_fc
+
+        betas = np.array(betas, dtype=np.float64)
+        self.betas = betas
+        assert len(betas.shape) == 1, "betas must be 1-D"
+        assert (betas > 0).all() and (betas <= 1).all()
+        self.num_timesteps = int(betas.shape[0])
+
+        alphas = 1.0 - betas
+        self.alphas_cumprod = np.cumprod(alphas, axis=0)
+        self.alphas_cumprod_prev = np.append(1.0, self.alphas_cumprod[:-1])
+        self.alphas_cumprod_next = np.append(self.alphas_cumprod[1:], 0.0)
+        assert self.alphas_cumprod_prev.shape == (self.num_timesteps,)
+        self.sqrt_alphas_cumprod = np.sqrt(self.alphas_cumprod)
+        self.sqrt_one_minus_alphas_cumprod = np.sqrt(1.0 - self.alphas_cumprod)
+        self.log_one_minus_alphas_cumprod = np.log(1.0 - self.alphas_cumprod)
+        self.sqrt_recip_alphas_cumprod = np.sqrt(1.0 / self.alphas_cumprod)
+        self.sqrt_recipm1_alphas_cumprod = np.sqrt(1.0 / self.alphas_cumprod - 1)
+        self.posterior_variance = betas * (1.0 - self.alphas_cumprod_prev) / (1.0 - self.alphas_cumprod)
+        self.posterior_log_variance_clipped = np.log(np.append(self.posterior_variance[1], self.posterior_variance[1:]))
+        self.posterior_mean_coef1 = betas * np.sqrt(self.alphas_cumprod_prev) / (1.0 - self.alphas_cumprod)
+        self.posterior_mean_coef2 = (1.0 - self.alphas_cumprod_prev) * np.sqrt(alphas) / (1.0 - self.alphas_cumprod)
+        self._coef_cache = {}
+
+    # ------------------------------------------------------------------ coefficient rows
+    def _model_variance_tables(self):
+        if self.model_var_type == ModelVarType.FIXED_LARGE:
+            v = np.append(self.posterior_variance[1], self.betas[1:])
+            return v, np.log(v)
+        if self.model_var_type == ModelVarType.FIXED_SMALL:
+            return self.posterior_variance, self.posterior_log_variance_clipped
+        raise NotImplementedError("learned variances are outside the sampling hot path")
+
+    def _check_supported(self):
+        if self.model_mean_type != ModelMeanType.START_X:
+            raise NotImplementedError("only ModelMeanType.START_X (the reference's configuration) is implemented")
+        self._model_variance_tables()
+
+    def coef_table(self, kind, device, eta=0.0):
+        """[num_timesteps, 8] fp32 rows consumed by gdx_sampler_update.  Every entry is rounded
+        exactly like the reference: fp64 table -> .float() (gaussian_diffusion.py:1595-1608), then
+        fp32 torch ops in the reference's order."""
+        key = (kind, str(device), float(eta))
+        if key in self._coef_cache:
+            return self._coef_cache[key]
+        self._check_supported()
+        f32 = lambda a: th.from_numpy(np.ascontiguousarray(a, dtype=np.float64)).float()   # noqa: E731
+        n = self.num_timesteps
+        nz = (th.arange(n) != 0).float()
+        c = th.zeros(n, 8, dtype=th.float32)
+        if kind == GDX_SAMPLER_P:
+            _, logvar = self._model_variance_tables()
+            c[:, 0] = f32(self.posterior_mean_coef1)
+            c[:, 1] = f32(self.posterior_mean_coef2)
+            c[:, 2] = nz * th.exp(0.5 * f32(logvar))
+        else:
+            ab, abp = f32(self.alphas_cumprod), f32(self.alphas_cumprod_prev)
+            sigma = eta * th.sqrt((1 - abp) / (1 - ab)) * th.sqrt(1 - ab / abp)
+            c[:, 0] = f32(self.sqrt_recip_alphas_cumprod)
+            c[:, 1] = f32(self.sqrt_recipm1_alphas_cumprod)
+            c[:, 2] = th.sqrt(abp)
+            c[:, 3] = th.sqrt(1 - abp - sigma ** 2)
+            c[:, 4] = nz * sigma
+        c[:, 5] = f32(self.sqrt_alphas_cumprod)
+        c[:, 6] = f32(self.sqrt_one_minus_alphas_cumprod)
+        c = c.to(device)
+        self._coef_cache[key] = c
+        return c
+
+    # ------------------------------------------------------------------ forward process
+    def q_sample(self, x_start, t, noise=None):
+        if noise is None:
+            noise = th.randn_like(x_start)
+        assert noise.shape == x_start.shape
+        E.require_device(x_start, "x_start")
+        tv = t.reshape(-1)
+        if not bool((tv == tv[0]).all()):
+            raise NotImplementedError("q_sample with per-sample timesteps is not on the sampling path")
+        coef = self.coef_table(GDX_SAMPLER_P, x_start.device)
+        return E.q_sample(E.f32c(x_start, "x_start"), E.f32c(noise, "noise"), coef, int(tv[0]))
+
+    # ------------------------------------------------------------------ one reverse step
+    def _scale_timesteps(self, t):
+        if self.rescale_timesteps:
+            return t.float() * (1000.0 / self.num_timesteps)
+        return t
+
+    def _call_model(self, model, x, t, model_kwargs):
+        return model(x, self._scale_timesteps(t), **model_kwargs)
+
+    def _step(self, kind, model, x, t, clip_denoised, denoised_fn, cond_fn, model_kwargs, eta=0.0, const_noise=False,
+              noise=None):
+        if cond_fn is not None:
+            raise NotImplementedError("cond_fn guidance is outside the sampling hot path (SURVEY.md 8f N4)")
+        if model_kwargs is None:
+            model_kwargs = {}
+        self._check_supported()
+        B, C = x.shape[:2]
+        assert t.shape == (B,)
+        model_output = self._call_model(model, x, t, model_kwargs)
+        y = model_kwargs["y"]                                             # KeyError like the reference (:307)
+        mask = motion = None
+        if "inpainting_mask" in y.keys() and "inpainted_motion" in y.keys():
+            mask, motion = y["inpainting_mask"], y["inpainted_motion"]
+            assert model_output.shape == mask.shape == motion.shape
+        x0 = E.f32c(model_output, "model output")
+        if denoised_fn is not None or clip_denoised:
+            # rare path (every reference caller passes clip_denoised=False, denoised_fn=None)
+            if mask is not None:
+                x0 = (x0 * ~mask) + (motion * mask)
+                mask = motion = None
+            if denoised_fn is not None:
+                x0 = denoised_fn(x0)
+            if clip_denoised:
+                x0 = x0.clamp(-1, 1)
+            x0 = x0.contiguous()
+        assert x0.shape == x.shape
+        if noise is None:
+            noise = th.randn_like(x)                                      # drawn even at t == 0 / eta == 0
+        if const_noise:
+            noise = noise[[0]].contiguous()
+        xc = E.f32c(x, "x")
+        out = th.empty_like(xc)
+        pred = th.empty_like(xc)
+        E.sampler_update(kind, self.coef_table(kind, x.device, eta), xc, x0, out, t=t.to(th.int64).contiguous(),
+                         inpaint_mask=mask.contiguous() if mask is not None else None,
+                         inpaint_motion=E.f32c(motion, "inpainted_motion") if motion is not None else None,
+                         noise=E.f32c(noise, "noise"), const_noise=const_noise, pred_xstart=pred)
+        return {"sample": out, "pred_xstart": pred}
+
+    def p_sample(self, model, x, t, clip_denoised=True, denoised_fn=None, cond_fn=None, model_kwargs=None,
+                 const_noise=False):
+        return self._step(GDX_SAMPLER_P, model, x, t, clip_denoised, denoised_fn, cond_fn, model_kwargs,
+                          const_noise=const_noise)
+
+    def ddim_sample(self, model, x, t, clip_denoised=True, denoised_fn=None, cond_fn=None, model_kwargs=None,
+                    eta=0.0):
+        return self._step(GDX_SAMPLER_DDIM, model, x, t, clip_denoised, denoised_fn, cond_fn, model_kwargs, eta=eta)
+
+    def p_mean_variance(self, model, x, t, clip_denoised=True, denoised_fn=None, model_kwargs=None):
+        """Dict API of the reference (:277-388).  mean = update with zero noise; the variance
+        entries are per-sample constants expanded to x's shape."""
+        zero = th.zeros_like(x)
+        r = self._step(GDX_SAMPLER_P, model, x, t, clip_denoised, denoised_fn, None, model_kwargs, noise=zero)
+        var, logvar = self._model_variance_tables()
+        ex = lambda a: th.from_numpy(a).to(x.device)[t].float().view(-1, *([1] * (x.dim() - 1))).expand(x.shape)  # noqa: E731
+        return {"mean": r["sample"], "variance": ex(var), "log_variance": ex(logvar), "pred_xstart": r["pred_xstart"]}
+
+    # ------------------------------------------------------------------ loops
+    def _prepare_loop(self, model, shape, noise, device, skip_timesteps, init_image, rng, philox_seed, sample_offset,
+                      noise_tape):
+        if device is None:
+            device = next(model.parameters()).device
+        assert isinstance(shape, (tuple, list))
+        if noise is not None:
+            img = noise
+        elif noise_tape is not None:
+            img = noise_tape[0]
+        elif rng == "philox":
+            img = E.randn(tuple(shape), device, philox_seed, sample_offset, 0)
+        else:
+            img = th.randn(*shape, device=device)
+        if skip_timesteps and init_image is None:
+            init_image = th.zeros_like(img)
+        indices = list(range(self.num_timesteps - skip_timesteps))[::-1]
+        if init_image is not None:
+            my_t = th.ones([shape[0]], device=device, dtype=th.long) * indices[0]
+            img = self.q_sample(init_image, my_t, img)
+        return device, img, indices
+
+    def _loop(self, kind, model, shape, noise, clip_denoised, denoised_fn, cond_fn, model_kwargs, device, progress,
+              eta, skip_timesteps, init_image, randomize_class, cond_fn_with_grad, const_noise, rng, philox_seed,
+              sample_offset, noise_tape, dump_steps=None):
+        if cond_fn is not None or cond_fn_with_grad or randomize_class:
+            raise NotImplementedError("cond_fn / randomize_class are outside the sampling hot path")
+        device, img, indices = self._prepare_loop(model, shape, noise, device, skip_timesteps, init_image, rng,
+                                                  philox_seed, sample_offset, noise_tape)
+        fused = (rng == "philox" or noise_tape is not None) and _is_native(model) and not clip_denoised \
+            and denoised_fn is None and not progress
+        if fused:
+            yield from self._fused_loop(kind, model, img, indices, model_kwargs, eta, const_noise, philox_seed,
+                                        sample_offset, noise_tape, dump_steps)
+            return
+        if progress:
+            from tqdm.auto import tqdm
+            indices = tqdm(indices)
+        for k, i in enumerate(indices):
+            t = th.full((shape[0],), i, device=device, dtype=th.long)
+            z = None
+            if noise_tape is not None:
+                z = noise_tape[1 + k]
+            elif rng == "philox":
+                z = E.randn(tuple(shape), device, philox_seed, 0 if const_noise else sample_offset, k + 1)
+            with th.no_grad():
+                out = self._step(kind, model, img, t, clip_denoised, denoised_fn, None, model_kwargs, eta=eta,
+                                 const_noise=const_noise, noise=z)
+            yield out
+            img = out["sample"]
+
+    def _fused_loop(self, kind, model, img, indices, model_kwargs, eta, const_noise, philox_seed, sample_offset,
+                    noise_tape, dump_steps):
+        """Whole loop inside libgdx (gdx_sample_loop); yields only the final state."""
+        from ..model.cfg_sampler import ClassifierFreeSampleModel
+        self._check_supported()
+        y = model_kwargs["y"]
+        inner = model.model if isinstance(model, ClassifierFreeSampleModel) else model
+        x = E.f32c(img, "x_T").clone()
+        B, J, F, T = x.shape
+        inner._check_inputs(x, y)
+        if hasattr(inner, "cl_head") and T % 10 != 0:
+            from ..model.mdm import _window_error
+            raise _window_error(T, 10)
+        eng = inner._get_engine(x.device)
+        eng.prepare(B, T)
+        eng.set_condition(y["seed"], y["mfcc"])
+        if isinstance(model, ClassifierFreeSampleModel):
+            mode, scale = GDX_CFG, E.f32c(y["scale"].reshape(-1), "y['scale']")
+        else:
+            mode, scale = (GDX_UNCOND if y.get("uncond", False) else GDX_COND), None
+        mask = motion = None
+        if "inpainting_mask" in y and "inpainted_motion" in y:
+            mask = E.require_device(y["inpainting_mask"], "inpainting_mask").to(th.bool).contiguous()
+            motion = E.f32c(y["inpainted_motion"], "inpainted_motion")
+        tape = None
+        if noise_tape is not None:
+            tape = E.f32c(noise_tape[1:1 + len(indices)], "noise_tape")
+            if const_noise:
+                tape = tape[:, :1].contiguous()
+        tmap = self._timestep_map()
+        dump = None
+        if dump_steps is not None:
+            dump_steps = sorted(int(s) for s in dump_steps if 0 <= int(s) < len(indices))
+            dump = th.empty(len(dump_steps), *x.shape, device=x.device, dtype=th.float32)
+        if self.rescale_timesteps:
+            raise NotImplementedError("rescale_timesteps=True is not used by the reference's sampler configuration")
+        eng.sample_loop(x, kind, mode, self.coef_table(kind, x.device, eta), tmap, indices[0], scale=scale,
+                        inpaint_mask=mask, inpaint_motion=motion, noise_tape=tape, const_noise=const_noise,
+                        philox_seed=philox_seed, sample_offset=sample_offset, dump=dump, dump_steps=dump_steps)
+        yield {"sample": x, "pred_xstart": None, "dump": dump, "fused": True}
+
+    def _timestep_map(self):
+        return list(range(self.num_timesteps))
+
+    def p_sample_loop(self, model, shape, noise=None, clip_denoised=True, denoised_fn=None, cond_fn=None,
+                      model_kwargs=None, device=None, progress=False, skip_timesteps=0, init_image=None,
+                      randomize_class=False, cond_fn_with_grad=False, dump_steps=None, const_noise=False,
+                      rng="torch", philox_seed=0, sample_offset=0, noise_tape=None):
+        final = None
+        dump = [] if dump_steps is not None else None
+        for i, sample in enumerate(self._loop(GDX_SAMPLER_P, model, shape, noise, clip_denoised, denoised_fn, cond_fn,
+                                              model_kwargs, device, progress, 0.0, skip_timesteps, init_image,
+                                              randomize_class, cond_fn_with_grad, const_noise, rng, philox_seed,
+                                              sample_offset, noise_tape, dump_steps)):
+            if sample.get("fused"):
+                if dump_steps is not None:
+                    return [d.clone() for d in sample["dump"]]
+                return sample["sample"]
+            if dump_steps is not None and i in dump_steps:
+                dump.append(sample["sample"].clone())
+            final = sample
+        if dump_steps is not None:
+            return dump
+        return final["sample"]
+
+    def p_sample_loop_progressive(self, model, shape, noise=None, clip_denoised=True, denoised_fn=None, cond_fn=None,
+                                  model_kwargs=None, device=None, progress=False, skip_timesteps=0, init_image=None,
+                                  randomize_class=False, cond_fn_with_grad=False, const_noise=False):
+        yield from self._loop(GDX_SAMPLER_P, model, shape, noise, clip_denoised, denoised_fn, cond_fn, model_kwargs,
+                              device, progress, 0.0, skip_timesteps, init_image, randomize_class, cond_fn_with_grad,
+                              const_noise, "torch", 0, 0, None)
+
+    def ddim_sample_loop(self, model, shape, noise=None, clip_denoised=True, denoised_fn=None, cond_fn=None,
+                         model_kwargs=None, device=None, progress=False, eta=0.0, skip_timesteps=0, init_image=None,
+                         randomize_class=False, cond_fn_with_grad=False, dump_steps=None, const_noise=False,
+                         rng="torch", philox_seed=0, sample_offset=0, noise_tape=None):
+        if dump_steps is not None:
+            raise NotImplementedError()                                   # reference :903-904
+        if const_noise == True:  # noqa: E712
+            raise NotImplementedError()                                   # reference :905-906
+        final = None
+        for sample in self._loop(GDX_SAMPLER_DDIM, model, shape, noise, clip_denoised, denoised_fn, cond_fn,
+                                 model_kwargs, device, progress, eta, skip_timesteps, init_image, randomize_class,
+                                 cond_fn_with_grad, False, rng, philox_seed, sample_offset, noise_tape):
+            final = sample
+        return final["sample"]
+
+    def ddim_sample_loop_progressive(self, model, shape, noise=None, clip_denoised=True, denoised_fn=None,
+                                     cond_fn=None, model_kwargs=None, device=None, progress=False, eta=0.0,
+                                     skip_timesteps=0, init_image=None, randomize_class=False,
+                                     cond_fn_with_grad=False):
+        yield from self._loop(GDX_SAMPLER_DDIM, model, shape, noise, clip_denoised, denoised_fn, cond_fn,
+                              model_kwargs, device, progress, eta, skip_timesteps, init_image, randomize_class,
+                              cond_fn_with_grad, False, "torch", 0, 0, None)
+
+    # ------------------------------------------------------------------ explicitly out of scope
+    def training_losses(self, *a, **k):
+        raise NotImplementedError("training is outside the sampling hot path (SURVEY.md section 2.1)")
+
+    def plms_sample_loop(self, *a, **k):
+        raise NotImplementedError("PLMS sampling is listed as 'next' (SURVEY.md 8f N4)")
+
+
+def _extract_into_tensor(arr, timesteps, broadcast_shape):
+    """Kept for API parity (reference :1595-1608)."""
+    res = th.from_numpy(arr).to(device=timesteps.device)[timesteps].float()
+    while len(res.shape) < len(broadcast_shape):
+        res = res[..., None]
+    return res.expand(broadcast_shape)

@@ -1,0 +1,175 @@
+"""Thin PyTorch-ROCm <-> libgdx.so glue: PyTorch supplies device memory and the stream,
+the C ABI (include/gdx.h) does all the arithmetic.  No torch compute happens here."""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import GDX_ARCH_MDM, GDX_ARCH_MDM_OLD, GDX_CFG, GDX_COND, GDX_UNCOND, GdxError  # noqa: F401
+
+MFCC_DIM = 26
+
+
+def _stream(device):
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def require_device(t, what):
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"{what} must be a torch.Tensor")
+    if t.device.type != "cuda":
+        raise GdxError(f"{what} is on {t.device}: the MI355X HIP path needs device tensors "
+                       f"(there is no CPU fallback in gesturediffusion_amd)")
+    return t
+
+
+def f32c(t, what):
+    require_device(t, what)
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t.contiguous()
+
+
+class Engine:
+    """One libgdx handle = one model instance on one device/stream."""
+
+    def __init__(self, arch, njoints, latent_dim, ff_size, num_layers, num_heads, seed_poses, cl_head=8, window=10):
+        self.lib = _lib.load()
+        self.cfg = _lib.Config(arch=arch, njoints=njoints, latent_dim=latent_dim, ff_size=ff_size,
+                               num_layers=num_layers, num_heads=num_heads, seed_poses=seed_poses, mfcc_dim=MFCC_DIM,
+                               cl_head=cl_head, window=window)
+        self.handle = C.c_void_p()
+        _lib.check(self.lib.gdx_create(C.byref(self.cfg), C.byref(self.handle)), self.lib)
+        self.device = None
+        self.shape = None          # (B, T) the workspace is sized for
+        self._cond_key = None
+        self._weights_key = None
+        self._keep = []            # tensors that must outlive enqueued work
+
+    def __del__(self):
+        try:
+            if getattr(self, "handle", None) and self.handle.value:
+                self.lib.gdx_destroy(self.handle)
+                self.handle = C.c_void_p()
+        except Exception:  # noqa: BLE001 - interpreter shutdown
+            pass
+
+    # ------------------------------------------------------------------ weights
+    def set_weight(self, name, t):
+        t = f32c(t, name)
+        shape = (C.c_int64 * t.dim())(*t.shape)
+        _lib.check(self.lib.gdx_set_weight(self.handle, name.encode(), _ptr(t), shape, t.dim(), _stream(t.device)),
+                   self.lib)
+        self.device = t.device
+        self._cond_key = None
+
+    def load_tensors(self, named):
+        for name, t in named.items():
+            self.set_weight(name, t)
+        _lib.check(self.lib.gdx_weights_ready(self.handle), self.lib)
+
+    # ------------------------------------------------------------------ shapes / conditioning
+    def prepare(self, batch, frames):
+        if self.shape != (batch, frames):
+            _lib.check(self.lib.gdx_prepare(self.handle, batch, frames), self.lib)
+            self.shape = (batch, frames)
+            self._cond_key = None
+
+    def set_condition(self, seed, mfcc):
+        """seed [B,J,1,P], mfcc [B,26,1,T]; cached on (pointer, version) so the per-step callable
+        protocol model(x, t, y=...) does not redo the step-invariant work."""
+        key = (seed.data_ptr(), seed._version, tuple(seed.shape), mfcc.data_ptr(), mfcc._version, tuple(mfcc.shape))
+        if key == self._cond_key:
+            return
+        seed_c, mfcc_c = f32c(seed, "y['seed']"), f32c(mfcc, "y['mfcc']")
+        _lib.check(self.lib.gdx_set_condition(self.handle, _ptr(seed_c), _ptr(mfcc_c), _stream(seed_c.device)),
+                   self.lib)
+        self._keep = [seed_c, mfcc_c]
+        self._cond_key = key
+
+    # ------------------------------------------------------------------ compute
+    def forward(self, x, timesteps, mode=GDX_COND, scale=None):
+        x = f32c(x, "x")
+        t = require_device(timesteps, "timesteps").to(torch.int64).contiguous()
+        out = torch.empty_like(x)
+        sc = f32c(scale, "y['scale']") if scale is not None else None
+        _lib.check(self.lib.gdx_forward(self.handle, _ptr(x), _ptr(t), mode, _ptr(sc), _ptr(out), _stream(x.device)),
+                   self.lib)
+        return out
+
+    def keep_taps(self, keep=True):
+        _lib.check(self.lib.gdx_set_keep_taps(self.handle, int(keep)), self.lib)
+        self._cond_key = None if keep else self._cond_key
+
+    def tap(self, which, rows, d, device):
+        out = torch.empty(rows, d, device=device, dtype=torch.float32)
+        _lib.check(self.lib.gdx_get_tap(self.handle, which, _ptr(out), out.numel(), _stream(device)), self.lib)
+        return out
+
+    def sample_loop(self, x, kind, mode, coef, timestep_map, first_index, scale=None, inpaint_mask=None,
+                    inpaint_motion=None, noise_tape=None, const_noise=False, philox_seed=0, sample_offset=0,
+                    dump=None, dump_steps=None):
+        """x is updated in place (x_T in, final sample out)."""
+        tmap = np.ascontiguousarray(np.asarray(timestep_map, dtype=np.int64))
+        ds = np.ascontiguousarray(np.asarray(dump_steps if dump_steps is not None else [], dtype=np.int32))
+        a = _lib.LoopArgs(kind=kind, mode=mode, num_steps=len(tmap), first_index=first_index, coef=coef.data_ptr(),
+                          timestep_map=tmap.ctypes.data, x=x.data_ptr(),
+                          scale=scale.data_ptr() if scale is not None else None,
+                          inpaint_mask=inpaint_mask.data_ptr() if inpaint_mask is not None else None,
+                          inpaint_motion=inpaint_motion.data_ptr() if inpaint_motion is not None else None,
+                          noise_tape=noise_tape.data_ptr() if noise_tape is not None else None,
+                          const_noise=int(const_noise), philox_seed=philox_seed, sample_offset=sample_offset,
+                          dump=dump.data_ptr() if dump is not None else None,
+                          dump_steps=ds.ctypes.data if len(ds) else None, n_dump=len(ds))
+        _lib.check(self.lib.gdx_sample_loop(self.handle, C.byref(a), _stream(x.device)), self.lib)
+        self._keep_loop = (tmap, ds)
+
+    def forward_flops(self, mode=GDX_COND):
+        f = C.c_double()
+        _lib.check(self.lib.gdx_forward_flops(self.handle, mode, C.byref(f)), self.lib)
+        return f.value
+
+    def bench_ffn_gemm(self, iters, device):
+        us = C.c_float()
+        _lib.check(self.lib.gdx_bench_ffn_gemm(self.handle, iters, C.byref(us), _stream(device)), self.lib)
+        return us.value
+
+
+# ---------------------------------------------------------------------- standalone kernels
+def sampler_update(kind, coef, x, x0_cond, out, t=None, step_index=0, x0_uncond=None, scale=None, inpaint_mask=None,
+                   inpaint_motion=None, noise=None, const_noise=False, philox_seed=0, sample_offset=0, rng_step=0,
+                   pred_xstart=None):
+    lib = _lib.load()
+    B, J, F, T = x.shape
+    a = _lib.UpdateArgs(kind=kind, batch=B, njoints=J * F, frames=T, coef=coef.data_ptr(),
+                        t=t.data_ptr() if t is not None else None, step_index=step_index, x=x.data_ptr(),
+                        x0_cond=x0_cond.data_ptr(), x0_uncond=x0_uncond.data_ptr() if x0_uncond is not None else None,
+                        scale=scale.data_ptr() if scale is not None else None,
+                        inpaint_mask=inpaint_mask.data_ptr() if inpaint_mask is not None else None,
+                        inpaint_motion=inpaint_motion.data_ptr() if inpaint_motion is not None else None,
+                        noise=noise.data_ptr() if noise is not None else None, const_noise=int(const_noise),
+                        philox_seed=philox_seed, sample_offset=sample_offset, rng_step=rng_step, out=out.data_ptr(),
+                        pred_xstart=pred_xstart.data_ptr() if pred_xstart is not None else None)
+    _lib.check(lib.gdx_sampler_update(C.byref(a), _stream(x.device)), lib)
+    return out
+
+
+def q_sample(x_start, noise, coef, idx):
+    lib = _lib.load()
+    out = torch.empty_like(x_start)
+    _lib.check(lib.gdx_q_sample(_ptr(x_start), _ptr(noise), _ptr(coef), idx, x_start.numel(), _ptr(out),
+                                _stream(x_start.device)), lib)
+    return out
+
+
+def randn(shape, device, philox_seed, sample_offset=0, rng_step=0):
+    lib = _lib.load()
+    out = torch.empty(shape, device=device, dtype=torch.float32)
+    per = out.numel() // shape[0]
+    _lib.check(lib.gdx_randn(_ptr(out), shape[0], per, philox_seed, sample_offset, rng_step, _stream(out.device)), lib)
+    return out

@@ -1,0 +1,89 @@
+"""Gesture sampling CLI: `python -m gesturediffusion_amd.sample.generate`.
+
+Keeps the reference CLI's flags and flow (`sample/generate.py:23-183`): args.json override,
+fixseed, model + diffusion factory, checkpoint load, optional classifier-free-guidance wrapper,
+then `chunks` autoregressive chunks, each a full sampling loop whose seed poses are the last
+`seed_poses` frames of the previous chunk (`:104-107`).  Dataset loading, BVH/MP4 writing and
+SMPL post-processing (GENEA data, bvhsdk, ffmpeg) are out of scope; with `--synthetic` the
+conditioning is N(0,1) and the script writes `results.npy` with the normalised poses.
+
+Multi-GPU: launch with `python -m torch.distributed.run --nproc-per-node N ...`; the batch is
+sharded across ranks and gathered once at the end of every chunk (RCCL over xGMI).
+"""
+import os
+
+import numpy as np
+import torch
+
+from ..model.cfg_sampler import ClassifierFreeSampleModel
+from ..utils import dist_util
+from ..utils.fixseed import fixseed
+from ..utils.init import init_state_dict, MFCC_DIM
+from ..utils.model_util import create_model_and_diffusion, load_model_wo_clip
+from ..utils.parser_util import generate_args
+
+
+def main(argv=None):
+    args = generate_args(argv)
+    fixseed(args.seed)
+    rank, world, device = dist_util.init_from_env()
+    if device.type != "cuda":
+        raise RuntimeError("sample.generate needs an MI355X GPU: the native path has no CPU fallback")
+    if not args.synthetic:
+        raise NotImplementedError("GENEA dataset loading is outside the hot path; use --synthetic "
+                                  "(checkpoints still load through --model_path)")
+    num_samples = min(args.num_samples if args.num_samples else 41, args.batch_size)
+    if args.dataset not in ("genea2022", "genea2023") and not args.synthetic_njoints:
+        args.synthetic_njoints = 263
+    args.mfcc_input = True if args.synthetic else args.mfcc_input
+
+    model, diffusion = create_model_and_diffusion(args, None)
+    if args.model_path:
+        state_dict = torch.load(args.model_path, map_location="cpu", weights_only=True)
+        load_model_wo_clip(model, state_dict)
+    else:
+        cfg = dict(arch=args.arch_version, njoints=model.njoints, nfeats=1, latent_dim=args.latent_dim, ff_size=1024,
+                   num_layers=args.layers, num_heads=4, seed_poses=args.seed_poses)
+        model.load_state_dict(init_state_dict(cfg, seed=args.seed), strict=False)
+    if args.guidance_param != 1:
+        model = ClassifierFreeSampleModel(model)
+    model.to(device)
+    model.eval()
+
+    lo, hi = dist_util.shard_range(num_samples, rank, world)
+    nb = hi - lo
+    J, T = model.njoints, args.num_frames
+    g = torch.Generator().manual_seed(args.seed)
+    seed_all = torch.randn(num_samples, J, 1, args.seed_poses, generator=g)
+    out_chunks = []
+    sample_fn = diffusion.p_sample_loop if args.sampler == "p" else diffusion.ddim_sample_loop
+    sample_out = None
+    for chunk in range(args.chunks):
+        mfcc = torch.randn(num_samples, MFCC_DIM, 1, T, generator=g)[lo:hi].to(device)
+        y = {"mfcc": mfcc, "seed": seed_all[lo:hi].to(device) if chunk == 0 else sample_out[..., -args.seed_poses:]}
+        if args.guidance_param != 1:
+            y["scale"] = torch.ones(nb, device=device) * args.guidance_param
+        kw = dict(clip_denoised=False, model_kwargs={"y": y}, skip_timesteps=0, init_image=None, progress=False,
+                  noise=None, rng=args.rng, philox_seed=args.seed + 1000 * chunk, sample_offset=lo)
+        if args.sampler == "p":
+            kw.update(dump_steps=None, const_noise=False)
+        else:
+            kw.update(eta=args.eta)
+        if rank == 0:
+            print(f"### Sampling chunk {chunk + 1} of {args.chunks}")
+        sample_out = sample_fn(model, (nb, J, 1, T), **kw)
+        full = dist_util.gather_samples(sample_out, num_samples)
+        if rank == 0:
+            out_chunks.append(full.cpu().numpy())
+    if rank == 0:
+        out_path = args.output_dir or os.path.join(os.getcwd(), f"samples_synthetic_seed{args.seed}")
+        os.makedirs(out_path, exist_ok=True)
+        motion = np.concatenate(out_chunks, axis=3)
+        np.save(os.path.join(out_path, "results.npy"), {"motion": motion, "num_samples": num_samples,
+                                                         "num_chunks": args.chunks}, allow_pickle=True)
+        print(f"saved results to [{os.path.join(out_path, 'results.npy')}] motion {motion.shape}")
+    return 0
+
+
+if __name__ == "__main__":
+    raise SystemExit(main())

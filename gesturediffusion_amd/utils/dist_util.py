@@ -1,0 +1,73 @@
+"""Device selection + one-process-per-GPU helpers.
+
+`setup_dist(device)` / `dev()` keep the reference's single-device semantics
+(`utils/dist_util.py:18-51`).  The reference never initialises a process group (its MPI/NCCL code
+is commented out, `:26-41`); multi-GPU here is new functionality around the hot path: samples of
+a batch are independent, so each rank samples a contiguous shard with zero communication and one
+RCCL gather over xGMI at the end returns the batch to rank 0.
+"""
+import os
+
+import torch as th
+import torch.distributed as dist
+
+GPUS_PER_NODE = 8
+used_device = 0
+
+
+def setup_dist(device=0):
+    global used_device
+    used_device = device
+
+
+def dev():
+    if th.cuda.is_available() and used_device >= 0:
+        return th.device(f"cuda:{used_device}")
+    return th.device("cpu")
+
+
+def load_state_dict(path, **kwargs):
+    kwargs.setdefault("weights_only", True)
+    return th.load(path, **kwargs)
+
+
+# --------------------------------------------------------------------------- multi-GPU sharding
+def init_from_env(backend=None):
+    """One process per GPU (torchrun / torch.distributed.run env).  Returns (rank, world, device)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    use_cuda = th.cuda.is_available()
+    device = th.device(f"cuda:{local}") if use_cuda else th.device("cpu")
+    if use_cuda:
+        th.cuda.set_device(device)
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        dist.init_process_group(backend or ("nccl" if use_cuda else "gloo"), rank=rank, world_size=world)
+    setup_dist(local if use_cuda else -1)
+    return rank, world, device
+
+
+def shard_range(total, rank, world):
+    """Contiguous shard [lo, hi) of `total` samples for `rank`; sizes differ by at most one."""
+    base, extra = divmod(total, world)
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+def gather_samples(local, total, dst=0):
+    """End-of-loop gather of per-rank sample shards [b_r, ...] to `dst` (the path's only
+    collective).  Uses all_gather on equal-size padded shards (RCCL over xGMI when on GPU)."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return local
+    world, rank = dist.get_world_size(), dist.get_rank()
+    sizes = [shard_range(total, r, world) for r in range(world)]
+    maxb = max(hi - lo for lo, hi in sizes)
+    pad = local.new_zeros((maxb,) + tuple(local.shape[1:]))
+    pad[: local.shape[0]] = local
+    bufs = [th.empty_like(pad) for _ in range(world)]
+    dist.all_gather(bufs, pad)
+    if rank != dst:
+        return None
+    return th.cat([b[: hi - lo] for b, (lo, hi) in zip(bufs, sizes)], dim=0)

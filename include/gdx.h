@@ -1,0 +1,178 @@
+/*
+ * gdx.h -- C ABI of libgdx.so: the MI355X-native (gfx950) diffusion-sampling hot path.
+ *
+ * Plain pointers and sizes only; every tensor argument is a DEVICE pointer owned by the
+ * caller (PyTorch-ROCm in this repo), fp32 unless stated, laid out exactly like the
+ * reference's tensors:
+ *     pose tensors  [B, J, 1, T]   (J = njoints * nfeats, nfeats must be 1; T fastest)
+ *     seed poses    [B, J, 1, P]   mfcc [B, 26, 1, T]   timesteps int64 [B]
+ * The library owns only its packed copy of the weights and its workspace.  One handle per
+ * (device, stream); not thread-safe per handle; no hidden device synchronisation;
+ * int status return (0 = ok, <0 = error, text via gdx_last_error()); no exceptions cross
+ * the ABI.  `stream` is a hipStream_t passed as void*.
+ *
+ * The reference has no plugin ABI for this path: it is pure Python.  Each
+ * entry point below names the reference Python interface it replaces; INTEGRATION.md shows
+ * the ctypes stub a reference maintainer would add.
+ */
+#ifndef GDX_H
+#define GDX_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct gdx_model* gdx_handle_t;
+
+enum { GDX_ARCH_MDM_OLD = 1,  /* model/mdm_old.py:11  MDM_Old ("V1") */
+       GDX_ARCH_MDM = 2 };    /* model/mdm.py:10      MDM     ("V2") */
+
+enum { GDX_COND = 0,          /* y without 'uncond'                     (model/mdm.py:111) */
+       GDX_UNCOND = 1,        /* y['uncond'] = True: seed poses zeroed  (model/mdm.py:127,242-250) */
+       GDX_CFG = 2 };         /* both passes + blend                    (model/cfg_sampler.py:23-28) */
+
+enum { GDX_SAMPLER_P = 0,     /* p_sample      diffusion/gaussian_diffusion.py:496-548 */
+       GDX_SAMPLER_DDIM = 1 };/* ddim_sample   diffusion/gaussian_diffusion.py:732-782 */
+
+/* Constructor arguments of MDM / MDM_Old that shape the computation
+ * (model/mdm.py:11-13, utils/model_util.py:18-34). */
+typedef struct {
+    int32_t arch;        /* GDX_ARCH_* */
+    int32_t njoints;     /* njoints * nfeats */
+    int32_t latent_dim;  /* d, multiple of 32 */
+    int32_t ff_size;     /* multiple of 32 */
+    int32_t num_layers;
+    int32_t num_heads;   /* d / num_heads must be a multiple of 32 */
+    int32_t seed_poses;
+    int32_t mfcc_dim;    /* 26 (model/mdm.py:57) */
+    int32_t cl_head;     /* 8  (model/mdm.py:71), V2 only */
+    int32_t window;      /* 10 (model/mdm.py:75), V2 only */
+} gdx_config_t;
+
+/* ---- lifetime ------------------------------------------------------------------------- */
+/* replaces MDM.__init__ / MDM_Old.__init__ (model/mdm.py:11-103, model/mdm_old.py:11-75). */
+int gdx_create(const gdx_config_t* cfg, gdx_handle_t* out);
+int gdx_destroy(gdx_handle_t h);
+/* last error text of the calling thread ("" if none). */
+const char* gdx_last_error(void);
+
+/* replaces nn.Module.load_state_dict for one entry (utils/model_util.py:6-9): `name` is the
+ * reference state-dict key, `dev_ptr` fp32 device data of `shape`; the library keeps its own
+ * packed (K-padded) copy.  Buffers `sequence_pos_encoder.pe` [max_len,1,d] (model/mdm.py:277-289)
+ * and, for V2, the rotary cos/sin tables are passed the same way under the names
+ * "sequence_pos_encoder.pe", "rope.cos", "rope.sin" ([max_pos, d/cl_head/2]). */
+int gdx_set_weight(gdx_handle_t h, const char* name, const float* dev_ptr,
+                   const int64_t* shape, int32_t ndim, void* stream);
+/* 0 when every parameter the architecture needs has been set, else <0 and the missing
+ * names in gdx_last_error(). */
+int gdx_weights_ready(gdx_handle_t h);
+
+/* ---- per-problem set-up ---------------------------------------------------------------- */
+/* Size the workspace for `batch` samples of `frames` frames (allocates; not capturable).
+ * V2 requires frames % window == 0 (the reference's einops rearrange raises,
+ * model/local_attention.py:104,110). */
+int gdx_prepare(gdx_handle_t h, int32_t batch, int32_t frames);
+
+/* Step-invariant conditioning (hoisted out of the 1000-step loop): seed-pose embedding for the
+ * cond and uncond passes (model/mdm.py:125-127), the MFCC slice of the input / project_to_lat
+ * linear (model/mdm.py:133-169, model/mdm_old.py:104-108).  seed [B,J,1,P], mfcc [B,26,1,T]. */
+int gdx_set_condition(gdx_handle_t h, const float* seed, const float* mfcc, void* stream);
+
+/* ---- denoiser -------------------------------------------------------------------------- */
+/* replaces MDM.forward / MDM_Old.forward / ClassifierFreeSampleModel.forward
+ * (model/mdm.py:105-224, model/mdm_old.py:84-122, model/cfg_sampler.py:23-28).
+ * x [B,J,1,T]; timesteps int64 [B] (already mapped through timestep_map); mode GDX_COND /
+ * GDX_UNCOND / GDX_CFG; scale [B] (GDX_CFG only, y['scale']); out [B,J,1,T] contiguous. */
+int gdx_forward(gdx_handle_t h, const float* x, const int64_t* timesteps, int32_t mode,
+                const float* scale, float* out, void* stream);
+
+/* Debug/parity taps: copy an internal activation to `out` (device).  which: 0 = encoder
+ * input [B,T+1,d], 1..L = output of encoder layer l [B,T+1,d] (only the most recent
+ * forward's last layer buffer is live unless keep_taps was set), see gdx_set_keep_taps. */
+int gdx_set_keep_taps(gdx_handle_t h, int32_t keep);
+int gdx_get_tap(gdx_handle_t h, int32_t which, float* out, int64_t count, void* stream);
+
+/* ---- sampler update -------------------------------------------------------------------- */
+/* One fused reverse-process update over [B,J,1,T] (replaces p_mean_variance's tail + p_sample /
+ * ddim_sample: gaussian_diffusion.py:307-311,374-376,524-548,748-782 and the CFG blend
+ * cfg_sampler.py:28).  Per element, with per-sample fp32 coefficient row c = coef[idx]:
+ *   x0  = x0_cond                       or  u + scale*(c - u)   when x0_uncond != NULL
+ *   x0  = x0*(1-m) + motion*m           when inpaint_mask != NULL
+ *   P   : out = (c[0]*x0 + c[1]*x) + c[2]*z
+ *   DDIM: eps = (c[0]*x - x0)/c[1];  out = (x0*c[2] + c[3]*eps) + c[4]*z
+ * with separately rounded products/sums (no FMA contraction), matching torch's op order.
+ * idx = t[b] if t != NULL else step_index.  z = noise[...] if noise != NULL, else Philox4x32-10
+ * N(0,1) keyed by (philox_seed; sample_offset+b [or sample 0 when const_noise]; rng_step; element).
+ * coef: device [num_steps][8] fp32 rows built by the host with the reference's own rounding
+ * (fp64 table -> .float(), gaussian_diffusion.py:1595-1608). */
+typedef struct {
+    int32_t kind;              /* GDX_SAMPLER_* */
+    int32_t batch, njoints, frames;
+    const float* coef;         /* [num_steps][8] */
+    const int64_t* t;          /* [B] or NULL */
+    int32_t step_index;        /* used when t == NULL */
+    const float* x;            /* x_t */
+    const float* x0_cond;      /* model output (cond pass) */
+    const float* x0_uncond;    /* NULL or uncond pass */
+    const float* scale;        /* [B] when x0_uncond != NULL */
+    const uint8_t* inpaint_mask;   /* NULL or bool bytes [B,J,1,T] */
+    const float* inpaint_motion;   /* [B,J,1,T] when mask != NULL */
+    const float* noise;        /* NULL -> Philox */
+    int32_t const_noise;       /* noise[[0]].repeat(B) (gaussian_diffusion.py:534-535) */
+    uint64_t philox_seed;
+    uint64_t sample_offset;    /* global index of sample 0 of this shard */
+    uint32_t rng_step;
+    float* out;                /* x_{t-1}; may alias x */
+    float* pred_xstart;        /* NULL or [B,J,1,T]: x0 after CFG/inpainting */
+} gdx_update_args_t;
+int gdx_sampler_update(const gdx_update_args_t* a, void* stream);
+
+/* q_sample (gaussian_diffusion.py:233-251): out = a*x_start + b*noise, a/b per-sample from
+ * coef rows (c[5], c[6]) at idx. */
+int gdx_q_sample(const float* x_start, const float* noise, const float* coef, int32_t idx,
+                 int64_t count, float* out, void* stream);
+
+/* Philox N(0,1) fill, same keying as gdx_sampler_update (rng_step) -- used for x_T. */
+int gdx_randn(float* out, int32_t batch, int64_t per_sample, uint64_t philox_seed,
+              uint64_t sample_offset, uint32_t rng_step, void* stream);
+
+/* ---- whole loop ------------------------------------------------------------------------ */
+/* replaces p_sample_loop / ddim_sample_loop (gaussian_diffusion.py:598-661, 879-926) in the
+ * configured mode (START_X, FIXED_SMALL, clip_denoised=False): iterates index = first_index
+ * .. 0, model timestep = timestep_map[index] (respace.py:124-129), all work enqueued on
+ * `stream` with no host synchronisation. */
+typedef struct {
+    int32_t kind;              /* GDX_SAMPLER_* */
+    int32_t mode;              /* GDX_COND / GDX_UNCOND / GDX_CFG */
+    int32_t num_steps;         /* rows of coef / timestep_map */
+    int32_t first_index;       /* num_steps - 1 - skip_timesteps */
+    const float* coef;         /* device [num_steps][8] */
+    const int64_t* timestep_map;   /* HOST [num_steps] */
+    float* x;                  /* in: x_T (or q_sample'd init), out: final sample */
+    const float* scale;        /* [B] for GDX_CFG */
+    const uint8_t* inpaint_mask;
+    const float* inpaint_motion;
+    const float* noise_tape;   /* NULL -> Philox; else [first_index+1][B,J,1,T], k-th executed step
+                                  ([first_index+1][1,J,1,T] when const_noise) */
+    int32_t const_noise;
+    uint64_t philox_seed;
+    uint64_t sample_offset;
+    float* dump;               /* NULL or [n_dump][B,J,1,T] */
+    const int32_t* dump_steps; /* HOST, ascending executed-step numbers */
+    int32_t n_dump;
+} gdx_loop_args_t;
+int gdx_sample_loop(gdx_handle_t h, const gdx_loop_args_t* a, void* stream);
+
+/* ---- measurement helpers (bench.py only) ------------------------------------------------ */
+/* Time `iters` launches of the FFN-1 GEMM (bias+GELU epilogue) of layer 0 on the current
+ * workspace shape with HIP events on `stream`; returns average microseconds per launch. */
+int gdx_bench_ffn_gemm(gdx_handle_t h, int32_t iters, float* avg_us, void* stream);
+/* Algorithmic FLOPs of one forward at the prepared shape (SURVEY.md 8d formula). */
+int gdx_forward_flops(gdx_handle_t h, int32_t mode, double* flops);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GDX_H */
