@@ -276,23 +276,4 @@ hipError_t launch_local_attention(const float* xseq, const float* cosT, const fl
     return hipGetLastError();
 }
 
-// classifier-free guidance blend (model/cfg_sampler.py:28), op order as the reference
-__global__ void cfg_blend_kernel(const float* __restrict__ c, const float* __restrict__ u,
-                                 const float* __restrict__ scale, float* __restrict__ out, long per_sample,
-                                 long total) {
-    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= total) return;
-    const float sc = scale[i / per_sample];
-    const float diff = __fsub_rn(c[i], u[i]);
-    out[i] = __fadd_rn(u[i], __fmul_rn(sc, diff));
-}
-
-hipError_t launch_cfg_blend(const float* c, const float* u, const float* scale, float* out, int B, int64_t per_sample,
-                            hipStream_t s) {
-    const long total = (long)B * per_sample;
-    hipLaunchKernelGGL(cfg_blend_kernel, dim3((total + 255) / 256), dim3(256), 0, s, c, u, scale, out,
-                       (long)per_sample, total);
-    return hipGetLastError();
-}
-
 }  // namespace gdx

@@ -9,8 +9,13 @@
 // contracted into FMA) in the reference's operation order, so given the same x0 / x / noise the
 // result is bit-identical to the torch expression.  Algorithmic bytes per element: read x, x0 (+ x0_u,
 // + tape noise), write x_{t-1}  ->  12-20 B.
+// NOTE: HIP's __fmul_rn/__fadd_rn are plain * and + and hipcc defaults to -ffp-contract=fast, so this
+// file is compiled with -ffp-contract=off (Makefile) AND carries the pragma below: bit-exactness against
+// the torch expression depends on no mul+add pair being fused.
 #include "gdx_internal.h"
 #include "../../include/gdx.h"
+
+#pragma clang fp contract(off)
 
 namespace gdx {
 
@@ -141,6 +146,25 @@ __global__ void randn_kernel(float* __restrict__ out, int batch, long per_sample
     const f32x4 z = philox_normal4(seed, sample_offset + (uint64_t)b, step, grp);
     const long e0 = (long)b * per_sample + 4L * grp;
     for (int i = 0; i < 4 && 4L * grp + i < per_sample; ++i) out[e0 + i] = z[i];
+}
+
+// classifier-free guidance blend (model/cfg_sampler.py:28), op order as the reference
+__global__ void cfg_blend_kernel(const float* __restrict__ c, const float* __restrict__ u,
+                                 const float* __restrict__ scale, float* __restrict__ out, long per_sample,
+                                 long total) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const float sc = scale[i / per_sample];
+    const float diff = __fsub_rn(c[i], u[i]);
+    out[i] = __fadd_rn(u[i], __fmul_rn(sc, diff));
+}
+
+hipError_t launch_cfg_blend(const float* c, const float* u, const float* scale, float* out, int B, int64_t per_sample,
+                            hipStream_t s) {
+    const long total = (long)B * per_sample;
+    hipLaunchKernelGGL(cfg_blend_kernel, dim3((total + 255) / 256), dim3(256), 0, s, c, u, scale, out,
+                       (long)per_sample, total);
+    return hipGetLastError();
 }
 
 }  // namespace gdx
