@@ -31,6 +31,22 @@ LOOP_STEPS = 1000
 F32_MFMA_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD
 
 
+def log(msg):
+    print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+
+
+def usable_cores():
+    """Host cores this process may actually use (affinity and cgroup quota, not the machine total)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:  # noqa: BLE001
+        pass
+    return max(1, n)
+
+
 def build_model(arch, J, d, layers, device, seed=0):
     from gesturediffusion_amd.model.mdm import MDM
     from gesturediffusion_amd.model.mdm_old import MDM_Old
@@ -64,7 +80,7 @@ def cpu_baseline(cfg, sd, B, T, seedp, mfcc, steps=6):
     from oracle import mdm_forward as omf
     from oracle import sampler as osamp
     from oracle import schedule as osch
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
     torch.set_num_threads(cores)
     tab, tmap = osch.make_tables("cosine", LOOP_STEPS, "")
     g = torch.Generator().manual_seed(0)
@@ -77,10 +93,12 @@ def cpu_baseline(cfg, sd, B, T, seedp, mfcc, steps=6):
         with torch.no_grad():
             x0 = omf.forward(sd, cfg, x, mapt[t], y)
             return osamp.p_sample_step(tab, x0, x, t, torch.randn(x.shape, generator=g))
+    log(f"cpu_baseline: {cores} threads, warm-up step ...")
     x = one(LOOP_STEPS - 1, x)       # warm-up (thread pool, allocator)
     t0 = time.perf_counter()
     for k in range(steps):
         x = one(LOOP_STEPS - 2 - k, x)
+        log(f"cpu_baseline: step {k + 1}/{steps} ({time.perf_counter() - t0:.1f} s)")
     sec = (time.perf_counter() - t0) / steps
     return {"value": B * T / (LOOP_STEPS * sec), "unit": "frames/s", "cores": cores, "kind": "port",
             "sample": f"{steps} of {LOOP_STEPS} denoise steps at the full batch ({B}x{cfg['njoints']}x1x{T}), "
@@ -102,7 +120,7 @@ def main():
     ap.add_argument("--cfg", action="store_true", help="ClassifierFreeSampleModel (cond+uncond double batch)")
     ap.add_argument("--sampler", default="p", choices=["p", "ddim"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-steps", type=int, default=6)
+    ap.add_argument("--cpu-steps", type=int, default=24)
     args = ap.parse_args()
 
     from gesturediffusion_amd.utils import dist_util
@@ -147,9 +165,11 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    log(f"rank {rank}/{world}: model on {device}, warm-up {args.warmup} steps ...")
     if args.warmup > 0:
         run(args.warmup)
     barrier()
+    log(f"timing {args.steps} steps ...")
     t0 = time.perf_counter()
     out = run(args.steps)
     barrier()
@@ -161,6 +181,7 @@ def main():
     assert torch.isfinite(out).all()
 
     ms_per_step = elapsed * 1e3 / args.steps
+    log(f"{elapsed:.3f} s for {args.steps} steps = {ms_per_step:.3f} ms/step")
     frames_per_sec = world * B * T / (LOOP_STEPS * ms_per_step * 1e-3)
 
     if rank == 0:

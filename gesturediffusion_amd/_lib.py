@@ -17,7 +17,7 @@ GDX_SAMPLER_P, GDX_SAMPLER_DDIM = 0, 1
 EXPORTS = [
     "gdx_create", "gdx_destroy", "gdx_last_error", "gdx_set_weight", "gdx_weights_ready", "gdx_prepare",
     "gdx_set_condition", "gdx_forward", "gdx_set_keep_taps", "gdx_get_tap", "gdx_sampler_update", "gdx_q_sample",
-    "gdx_randn", "gdx_sample_loop", "gdx_bench_ffn_gemm", "gdx_forward_flops",
+    "gdx_randn", "gdx_sample_loop", "gdx_bench_ffn_gemm", "gdx_bench_gemm", "gdx_forward_flops",
 ]
 
 
@@ -63,6 +63,9 @@ def load():
         raise GdxError(f"HIP library not built: {LIB_PATH} is missing "
                        f"(run `python __graft_entry__.py` or `make -C gesturediffusion_amd/csrc`)")
     try:
+        # torch ships its own HIP runtime; importing it first makes libgdx.so bind to that same
+        # runtime instance, so torch's streams / device pointers are valid inside the library.
+        import torch  # noqa: F401
         lib = C.CDLL(LIB_PATH)
     except OSError as e:  # missing libamdhip64, wrong arch ...
         raise GdxError(f"cannot load {LIB_PATH}: {e}") from e
@@ -84,6 +87,7 @@ def load():
         "gdx_sample_loop": [vp, C.POINTER(LoopArgs), vp],
         "gdx_bench_ffn_gemm": [vp, i32, C.POINTER(C.c_float), vp],
         "gdx_forward_flops": [vp, i32, C.POINTER(C.c_double)],
+        "gdx_bench_gemm": [i32, i32, i32, i32, i32, C.POINTER(C.c_float), vp],
     }
     for name, args in sigs.items():
         fn = getattr(lib, name)

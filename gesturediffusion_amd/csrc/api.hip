@@ -540,3 +540,43 @@ extern "C" int gdx_bench_ffn_gemm(gdx_handle_t h, int32_t iters, float* avg_us, 
     (void)hipEventDestroy(e1);
     return 0;
 }
+
+// Stand-alone GEMM timing on scratch buffers (measurement helper for tools/gemm_sweep.py and bench.py).
+extern "C" int gdx_bench_gemm(int32_t M, int32_t N, int32_t K, int32_t epi, int32_t iters, float* avg_us, void* stream) {
+    if (!avg_us || M <= 0 || N <= 0 || K <= 0 || K % 32 || iters <= 0) return fail("gdx_bench_gemm: bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    hipError_t e = gemm_init();
+    if (e != hipSuccess) return fail(std::string("gemm_init: ") + hipGetErrorString(e));
+    const int npad = round_up(N, 128);
+    float *A = nullptr, *W = nullptr, *bias = nullptr, *R = nullptr, *C = nullptr;
+    std::vector<void*> pool;
+    if (dev_alloc(pool, (void**)&A, sizeof(float) * (size_t)M * K) || dev_alloc(pool, (void**)&W, sizeof(float) * (size_t)npad * K) ||
+        dev_alloc(pool, (void**)&bias, sizeof(float) * npad) || dev_alloc(pool, (void**)&R, sizeof(float) * (size_t)M * N) ||
+        dev_alloc(pool, (void**)&C, sizeof(float) * (size_t)M * N)) {
+        free_pool(pool);
+        return -1;
+    }
+    // non-trivial operand values (zero operands raise the clock: cdna_hip_programming.md rule 25)
+    HIPCHK(gdx_randn(A, 1, (int64_t)M * K, 1, 0, 0, stream) ? hipErrorUnknown : hipSuccess);
+    HIPCHK(gdx_randn(W, 1, (int64_t)npad * K, 2, 0, 0, stream) ? hipErrorUnknown : hipSuccess);
+    HIPCHK(gdx_randn(R, 1, (int64_t)M * N, 3, 0, 0, stream) ? hipErrorUnknown : hipSuccess);
+    HIPCHK(gdx_randn(bias, 1, npad, 4, 0, 0, stream) ? hipErrorUnknown : hipSuccess);
+    GemmParams p{A, K, W, K, bias, R, N, nullptr, 0, C, N, M, N, K, 1, 1};
+    hipEvent_t e0, e1;
+    HIPCHK(hipEventCreate(&e0));
+    HIPCHK(hipEventCreate(&e1));
+    for (int i = 0; i < 3; ++i)
+        if (gemm(A_ROWS, B_WEIGHT, OUT_ROWS, epi, p, s)) { free_pool(pool); return -1; }
+    HIPCHK(hipEventRecord(e0, s));
+    for (int i = 0; i < iters; ++i)
+        if (gemm(A_ROWS, B_WEIGHT, OUT_ROWS, epi, p, s)) { free_pool(pool); return -1; }
+    HIPCHK(hipEventRecord(e1, s));
+    HIPCHK(hipEventSynchronize(e1));
+    float ms = 0.f;
+    HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+    *avg_us = ms * 1000.0f / (float)iters;
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    free_pool(pool);
+    return 0;
+}

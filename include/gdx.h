@@ -169,6 +169,9 @@ int gdx_sample_loop(gdx_handle_t h, const gdx_loop_args_t* a, void* stream);
 /* Time `iters` launches of the FFN-1 GEMM (bias+GELU epilogue) of layer 0 on the current
  * workspace shape with HIP events on `stream`; returns average microseconds per launch. */
 int gdx_bench_ffn_gemm(gdx_handle_t h, int32_t iters, float* avg_us, void* stream);
+/* Time `iters` launches of a stand-alone C[M,N] = A[M,K] W[N,K]^T GEMM with epilogue `epi`
+ * (0 bias, 1 bias+GELU, 2 bias+residual) on scratch buffers filled with N(0,1). */
+int gdx_bench_gemm(int32_t M, int32_t N, int32_t K, int32_t epi, int32_t iters, float* avg_us, void* stream);
 /* Algorithmic FLOPs of one forward at the prepared shape (SURVEY.md 8d formula). */
 int gdx_forward_flops(gdx_handle_t h, int32_t mode, double* flops);
 

@@ -310,6 +310,16 @@ def gen_negative(mods, out):
             f.write(f"{k}={v}\n")
 
 
+def gen_state_dict_keys(mods, out):
+    """State-dict key -> shape listing of the reference modules (drop-in contract)."""
+    with open(os.path.join(out, "state_dict_keys.txt"), "w") as f:
+        for arch, J, d in (("mdm", 263, 512), ("mdm_old", 263, 512), ("mdm", 498, 256)):
+            cfg = real_cfg(arch, J, d, L=2)
+            m = build_ref_model(mods, cfg, init_state_dict(cfg, seed=0))
+            for k, v in m.state_dict().items():
+                f.write(f"{arch} {J} {d} {k} {'x'.join(str(i) for i in v.shape)}\n")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--ref", default="/root/reference")
@@ -323,6 +333,7 @@ def main():
     gen_loops_tiny(mods, args.out)
     gen_real_shapes(mods, args.out)
     gen_negative(mods, args.out)
+    gen_state_dict_keys(mods, args.out)
     for f in sorted(os.listdir(args.out)):
         print(f, os.path.getsize(os.path.join(args.out, f)))
 
