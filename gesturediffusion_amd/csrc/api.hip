@@ -5,6 +5,7 @@
 #include "../../include/gdx.h"
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <set>
@@ -50,6 +51,7 @@ struct Layer {
 }  // namespace gdx
 
 using namespace gdx;
+namespace gdx { extern unsigned long long* g2_dbg_buf; }
 
 struct gdx_model {
     gdx_config_t cfg;
@@ -300,14 +302,15 @@ extern "C" int gdx_prepare(gdx_handle_t h, int32_t batch, int32_t frames) {
     h->taps.clear();
     h->temb_table = nullptr; h->temb_table_rows = 0; h->tmap_dev = nullptr;
     h->B = batch; h->T = frames; h->S = frames + 1; h->cond_set = false;
-    const size_t B2 = 2 * (size_t)batch, N = B2 * h->S, d = h->d;
+    // +128 rows: the persistent GEMM reads / stores whole tiles past the last logical row (gemm2.hip)
+    const size_t B2 = 2 * (size_t)batch, N = B2 * h->S + 128, d = h->d;
     auto A = [&](float** p, size_t n) { return dev_alloc(h->ws_allocs, (void**)p, n * sizeof(float)); };
     if (A(&h->xa, N * d) || A(&h->xb, N * d) || A(&h->qkv, N * 3 * d) || A(&h->ctx, N * d) || A(&h->tmp, N * d) ||
         A(&h->ffb, N * h->ff) || A(&h->addend, N * d) || A(&h->seed_cat, B2 * d) || A(&h->temb_in, B2 * d) ||
         A(&h->temb_h, B2 * d) || A(&h->temb, B2 * d) || A(&h->coa, B2 * d) || A(&h->c2, B2 * d) ||
         A(&h->x0, B2 * h->J * (size_t)frames))
         return -1;
-    if (h->cfg.arch == GDX_ARCH_MDM && (A(&h->emb_pose, B2 * frames * d) || A(&h->xseq, B2 * frames * d))) return -1;
+    if (h->cfg.arch == GDX_ARCH_MDM && (A(&h->emb_pose, (B2 * frames + 128) * d) || A(&h->xseq, (B2 * frames + 128) * d))) return -1;
     if (h->keep_taps) {
         h->taps.resize(h->L + 1);
         for (auto& t : h->taps)
@@ -364,7 +367,12 @@ extern "C" int gdx_set_condition(gdx_handle_t h, const float* seed, const float*
 }
 
 static int gemm(int am, int bm, int om, int ep, const GemmParams& p, hipStream_t s) {
-    hipError_t e = launch_gemm(am, bm, om, ep, p, s);
+    static const bool force_v1 = getenv("GDX_GEMM_V1") != nullptr;   // A/B switch for measurements
+    hipError_t e;
+    if (!force_v1 && am == A_ROWS && bm == B_WEIGHT && om == OUT_ROWS && gemm2_supported(ep, p))
+        e = launch_gemm2(ep, p, s);
+    else
+        e = launch_gemm(am, bm, om, ep, p, s);
     if (e != hipSuccess) return fail(std::string("launch_gemm: ") + hipGetErrorString(e));
     return 0;
 }
@@ -399,14 +407,15 @@ static int forward_core(gdx_model* h, const float* x, const float* temb, int tst
         p = GemmParams{h->xa, d, ly.qkv.w, ly.qkv.kpad, ly.qkv.bias, nullptr, 0, nullptr, 0, h->qkv, 3 * d, N, 3 * d, d, T, B};
         if (gemm(A_ROWS, B_WEIGHT, OUT_ROWS, EPI_BIAS, p, s)) return -1;
         HIPCHK(launch_attention(h->qkv, h->ctx, Beff, S, h->H, d, s));
-        p = GemmParams{h->ctx, d, ly.out.w, ly.out.kpad, ly.out.bias, h->xa, d, nullptr, 0, h->tmp, d, N, d, d, T, B};
-        if (gemm(A_ROWS, B_WEIGHT, OUT_ROWS, EPI_RES, p, s)) return -1;
-        HIPCHK(launch_layernorm(h->tmp, ly.g1, ly.b1, h->xb, N, d, s));
+        // x = LN1(x + out_proj(ctx)): the residual add rides in the LayerNorm kernel (see gemm2.hip)
+        p = GemmParams{h->ctx, d, ly.out.w, ly.out.kpad, ly.out.bias, nullptr, 0, nullptr, 0, h->tmp, d, N, d, d, T, B};
+        if (gemm(A_ROWS, B_WEIGHT, OUT_ROWS, EPI_BIAS, p, s)) return -1;
+        HIPCHK(launch_layernorm(h->tmp, h->xa, ly.g1, ly.b1, h->xb, N, d, s));
         p = GemmParams{h->xb, d, ly.ff1.w, ly.ff1.kpad, ly.ff1.bias, nullptr, 0, nullptr, 0, h->ffb, h->ff, N, h->ff, d, T, B};
         if (gemm(A_ROWS, B_WEIGHT, OUT_ROWS, EPI_GELU, p, s)) return -1;
-        p = GemmParams{h->ffb, h->ff, ly.ff2.w, ly.ff2.kpad, ly.ff2.bias, h->xb, d, nullptr, 0, h->tmp, d, N, d, h->ff, T, B};
-        if (gemm(A_ROWS, B_WEIGHT, OUT_ROWS, EPI_RES, p, s)) return -1;
-        HIPCHK(launch_layernorm(h->tmp, ly.g2, ly.b2, h->xa, N, d, s));
+        p = GemmParams{h->ffb, h->ff, ly.ff2.w, ly.ff2.kpad, ly.ff2.bias, nullptr, 0, nullptr, 0, h->tmp, d, N, d, h->ff, T, B};
+        if (gemm(A_ROWS, B_WEIGHT, OUT_ROWS, EPI_BIAS, p, s)) return -1;
+        HIPCHK(launch_layernorm(h->tmp, h->xb, ly.g2, ly.b2, h->xa, N, d, s));
         if (h->keep_taps)
             HIPCHK(hipMemcpyAsync(h->taps[l + 1], h->xa, sizeof(float) * (size_t)N * d, hipMemcpyDeviceToDevice, s));
     }
@@ -550,9 +559,9 @@ extern "C" int gdx_bench_gemm(int32_t M, int32_t N, int32_t K, int32_t epi, int3
     const int npad = round_up(N, 128);
     float *A = nullptr, *W = nullptr, *bias = nullptr, *R = nullptr, *C = nullptr;
     std::vector<void*> pool;
-    if (dev_alloc(pool, (void**)&A, sizeof(float) * (size_t)M * K) || dev_alloc(pool, (void**)&W, sizeof(float) * (size_t)npad * K) ||
+    if (dev_alloc(pool, (void**)&A, sizeof(float) * (size_t)(M + 128) * K) || dev_alloc(pool, (void**)&W, sizeof(float) * (size_t)npad * K) ||
         dev_alloc(pool, (void**)&bias, sizeof(float) * npad) || dev_alloc(pool, (void**)&R, sizeof(float) * (size_t)M * N) ||
-        dev_alloc(pool, (void**)&C, sizeof(float) * (size_t)M * N)) {
+        dev_alloc(pool, (void**)&C, sizeof(float) * (size_t)(M + 128) * N)) {
         free_pool(pool);
         return -1;
     }
@@ -577,6 +586,27 @@ extern "C" int gdx_bench_gemm(int32_t M, int32_t N, int32_t K, int32_t epi, int3
     *avg_us = ms * 1000.0f / (float)iters;
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
+    if (getenv("GDX_GEMM_DEBUG")) {      // one extra launch with in-kernel stamps (diagnostic build path only)
+        unsigned long long* d = nullptr;
+        if (!dev_alloc(pool, (void**)&d, 512)) {
+            (void)hipMemsetAsync(d, 0, 512, s);
+            g2_dbg_buf = d;
+            (void)gemm(A_ROWS, B_WEIGHT, OUT_ROWS, epi, p, s);
+            g2_dbg_buf = nullptr;
+            unsigned long long h[40] = {0};
+            (void)hipMemcpyAsync(h, d, 320, hipMemcpyDeviceToHost, s);
+            (void)hipStreamSynchronize(s);
+            if (h[9]) {
+                fprintf(stderr, "[gemm2 stamps] barrier B of step 40, cycles relative to wave0 release (arrive/release):");
+                for (int w = 0; w < 12; ++w)
+                    fprintf(stderr, " w%d:%lld/%lld", w, (long long)(h[8 + 2 * w] - h[9]), (long long)(h[9 + 2 * w] - h[9]));
+                fprintf(stderr, "\n");
+            }
+            if (h[2])
+                fprintf(stderr, "[gemm2 stamps] block0 consumer: %llu cycles, %.2f us, %llu K-steps -> %.0f cycles/step, clock %.2f GHz\n",
+                        h[0], h[1] / 100.0, h[2], (double)h[0] / h[2], h[1] ? (double)h[0] / (h[1] * 10.0) : 0.0);
+        }
+    }
     free_pool(pool);
     return 0;
 }

@@ -35,12 +35,17 @@ struct GemmParams {
 hipError_t gemm_init();   // raises the dynamic-LDS limit of every instantiation
 hipError_t launch_gemm(int amode, int bmode, int omode, int epi, const GemmParams& p, hipStream_t s);
 
+// persistent wave-specialised variant for A_ROWS x B_WEIGHT -> OUT_ROWS (gemm2.hip)
+bool gemm2_supported(int epi, const GemmParams& p);
+hipError_t launch_gemm2(int epi, const GemmParams& p, hipStream_t s);
+
 // ---- attention (attention.hip) -----------------------------------------------------------
 // qkv [B*S][3d] (q | k | v, heads contiguous inside each), ctx [B*S][d]
 hipError_t launch_attention(const float* qkv, float* ctx, int B, int S, int H, int d, hipStream_t s);
 
 // ---- misc (misc.hip) ---------------------------------------------------------------------
-hipError_t launch_layernorm(const float* x, const float* gamma, const float* beta, float* out,
+// out = LayerNorm(x + res) (res may be nullptr)
+hipError_t launch_layernorm(const float* x, const float* res, const float* gamma, const float* beta, float* out,
                             int rows, int d, hipStream_t s);
 // out[m][n] = act(sum_k A[m*lda+k] * W[n*ldw+k] + bias[n]);  act: 0 none, 1 SiLU.  K arbitrary.
 hipError_t launch_small_linear(const float* A, int lda, const float* W, int ldw, const float* bias,

@@ -1,0 +1,334 @@
+// Persistent fp32 MFMA GEMM for the encoder projections:  C = A * W^T + bias (optionally GELU),
+// A [M][K] row-major activations, W packed weights [N(pad)][K] (both K-contiguous), C [M][N].
+//
+// Why a second kernel, and why it looks like this (all measured on MI355X; tools/gemm_sweep.py, tools/gemm_one.py
+// and the s_memtime stamps behind GDX_GEMM_DEBUG):
+//   * the 128x128 kernel of gemm.hip sustains 81-83 % of the fp32 MFMA peak at large K, but the denoiser's
+//     GEMMs have K = 512/1024 and M = B*(T+1) = 12 608 = 64*197 (197 prime): 128-row tiles give 792 tiles for
+//     512 block slots (a quarter of the chip idles in the last round), and co-resident blocks run in lockstep so
+//     every tile's prologue/epilogue is exposed -> 48-55 % of peak;
+//   * a first persistent version with separate loader / epilogue waves did NOT hide that work: on gfx950 the fp32
+//     MFMA (v_mfma_f32_16x16x4_f32, 64 FLOP/clk/SIMD = the fp32 VALU rate) does not overlap other waves' vector
+//     work the way the bf16 MFMA does -- every VALU / LDS-store instruction any wave of the SIMD issued showed up
+//     as lost MFMA issue time (idle helpers: 2990 cycles per 2560-cycle K step; helpers that only re-wrote LDS:
+//     3370; with their loads, address arithmetic and epilogue: 3600-3900).  So the design goal is the minimum
+//     number of non-MFMA vector instructions per MFMA, not overlap:
+//   * operand staging is LDS-DMA (buffer_load_dwordx4 ... lds) with the tile / K offset in an SGPR soffset and a
+//     per-lane, tile-independent voffset: zero VALU instructions, zero VGPRs, no ds_write.  A 4-stage LDS ring
+//     keeps two K slabs of DMA in flight per CU across barriers (counted s_waitcnt vmcnt(N), raw s_barrier);
+//   * no LDS C-stage and no helper waves: 4 waves, each owning all BM rows x BN/4 columns, run ds_read_b128 +
+//     MFMA, issue their share of the DMA, and store their accumulators straight from registers; the bias vector
+//     is copied to LDS once per launch so the tile loop contains NO ordinary global load (one would make hipcc
+//     drain the DMA pipeline with vmcnt(0));
+//   * the residual add of the out-proj / FFN-2 GEMMs moved into the LayerNorm kernel that follows (one extra
+//     operand stream in an HBM-bound kernel instead of 40 scattered loads per lane in the MFMA-bound one);
+//   * GELU uses a 12-instruction erf (Abramowitz-Stegun 7.1.26, |abs err| <= 1.5e-7) instead of the ~50-instruction
+//     libm erff: at fp32 MFMA rates the epilogue VALU is not free;
+//   * tile height is a multiple of 16 rows, chosen per problem so that tiles / CUs lands just below an integer:
+//     BM = 80 turns M = 12 608 into 158 row tiles; with BN = 128 (N = 1024) or 64 (N = 512) that is 1 264 tiles
+//     = 4.94 per CU (98.8 % balance).  Tiles are walked lid, lid+G, ... in an XCD-aware order (the column tiles of
+//     one row panel run on one XCD and share its L2).
+// Contract with the caller (api.hip): A and C have at least 128 readable / writable rows beyond M (workspace
+// padding): the last row tile reads and stores whole tiles, its surplus rows are garbage that nothing consumes.
+// Summation order per output element is k-slab by k-slab and does not depend on the tile shape, so results are
+// independent of batch size / tile choice (tests/test_gpu_parity.py::test_full_size_properties_config2).
+#include "gdx_internal.h"
+
+#include <cstdio>
+#include <cstdlib>
+
+namespace gdx {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+// erf(x), Abramowitz & Stegun 7.1.26 (max abs error 1.5e-7), branch-free
+__device__ __forceinline__ float erf_as(float x) {
+    const float ax = fabsf(x);
+    const float t = __frcp_rn(fmaf(0.3275911f, ax, 1.0f));
+    float pl = fmaf(1.061405429f, t, -1.453152027f);
+    pl = fmaf(pl, t, 1.421413741f);
+    pl = fmaf(pl, t, -0.284496736f);
+    pl = fmaf(pl, t, 0.254829592f);
+    const float r = 1.0f - pl * t * __expf(-ax * ax);
+    return copysignf(r, x);
+}
+__device__ __forceinline__ float gelu_fast(float x) { return x * 0.5f * (1.0f + erf_as(x * 0.70710678118654752440f)); }
+
+template <int N>
+__device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+template <int MB, int NBW, int BK, int NST>
+__global__ __launch_bounds__(512, 1) void gemm4_kernel(const GemmParams p, const int epi, const int ntn,
+                                                       const int ntiles, unsigned long long* dbg) {
+#if defined(__HIP_DEVICE_COMPILE__)   // the host pass only needs the launch stub (the buffer-resource builtins are device-only)
+    constexpr int BM = MB * 16, WN = NBW * 16, BN = WN * 4;
+    constexpr int ST = BK + 8;                                // LDS row stride (floats): conflict-free b128 reads
+    constexpr int ROWB = ST * 4;                              // bytes per LDS row (BK*4 data + 32 pad)
+    constexpr int A_BYTES = (BM * ROWB + 1023) / 1024 * 1024;
+    constexpr int W_BYTES = (BN * ROWB + 1023) / 1024 * 1024;
+    constexpr int STAGE_BYTES = A_BYTES + W_BYTES;
+    constexpr int A_P = A_BYTES / 1024, P = STAGE_BYTES / 1024;   // 1 KiB DMA pieces per slab
+    constexpr int PW = (P + 3) / 4;                           // pieces per wave per slab
+    constexpr int KK = BK / 16;                               // 16-deep fragment groups per slab
+    constexpr int NSTORE = MB * NBW * 4;                      // epilogue store instructions per wave per tile
+    constexpr int VM_STEP = (NST - 3) * PW;                   // DMA pieces younger than the slab a step must wait for
+    static_assert(W_BYTES == BN * ROWB, "W region must have no gap (rows past N are not padded)");
+    static_assert(NST >= 3, "ring needs >= 3 stages (fragments of slab g+1 are read during step g)");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* const bias_lds = reinterpret_cast<float*>(smem + NST * STAGE_BYTES);
+
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid) >> 6;
+    const int lane = tid & 63;
+    const int l15 = lane & 15, lq = lane >> 4;
+    const int G = gridDim.x;
+    int lid;
+    {   // XCD-aware bijective remap (blocks b, b+8, ... share an XCD)
+        const int bid = blockIdx.x, q = G >> 3, r = G & 7, xcd = bid & 7, idx = bid >> 3;
+        lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int my_tiles = lid < ntiles ? (ntiles - lid + G - 1) / G : 0;
+    const int nk = p.K / BK;
+    const int total = my_tiles * nk;
+    if (total == 0) return;
+
+    // bias -> LDS once (the only ordinary global loads of the kernel, before any DMA is in flight)
+    for (int i = tid; i < p.N; i += 512) bias_lds[i] = p.bias ? p.bias[i] : 0.0f;
+
+    // ---- DMA set-up: descriptors (wave-uniform) and tile-independent per-lane offsets ------------------------
+    const auto rsrcA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.A), (short)0, 0x7ffffff0, 0x00020000);
+    const auto rsrcW = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.W), (short)0, 0x7ffffff0, 0x00020000);
+    int voff[PW];
+#pragma unroll
+    for (int i = 0; i < PW; ++i) {
+        int piece = (wave & 3) + 4 * i;
+        piece = piece < P ? piece : P - 1;                    // surplus issues re-write the last piece (same bytes)
+        const bool isA = piece < A_P;
+        const int o = (isA ? piece : piece - A_P) * 1024 + 16 * lane;   // byte offset inside the A / W region
+        const int row = o / ROWB;
+        int c = (o % ROWB) / 16;
+        c = c < BK / 4 ? c : 0;                               // the two pad lanes of a row re-read its first 16 B
+        voff[i] = (row * (isA ? p.lda : p.ldw) + c * 4) * 4;
+    }
+    int ld_tile_i = 0, ld_ks = 0;                             // next slab to issue
+    int ld_m0 = (lid / ntn) * BM, ld_n0 = (lid % ntn) * BN;
+    auto issue = [&](int stage) {                             // exactly PW DMA instructions, no VALU
+        const int a_so = (ld_m0 * p.lda + ld_ks * BK) * 4;
+        const int w_so = (ld_n0 * p.ldw + ld_ks * BK) * 4;
+        char* sb = smem + stage * STAGE_BYTES;
+#pragma unroll
+        for (int i = 0; i < PW; ++i) {
+            int piece = (wave & 3) + 4 * i;
+            piece = piece < P ? piece : P - 1;
+            if (piece < A_P)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcA, (lds_ptr_t)(sb + piece * 1024), 16, voff[i], a_so, 0, 0);
+            else
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcW, (lds_ptr_t)(sb + A_BYTES + (piece - A_P) * 1024), 16,
+                                                         voff[i], w_so, 0, 0);
+        }
+        asm volatile("" ::: "memory");                        // keep the DMA issue where it is (counted waits)
+        if (++ld_ks == nk) {
+            ld_ks = 0;
+            ++ld_tile_i;
+            const int ti = ld_tile_i < my_tiles ? ld_tile_i : my_tiles - 1;   // past the end: harmless re-reads
+            const int tile = lid + ti * G;
+            ld_m0 = (tile / ntn) * BM;
+            ld_n0 = (tile % ntn) * BN;
+        }
+    };
+
+    if (wave >= 4) {
+        // ================================================================== loader waves: DMA issue only
+        // (an LDS-DMA instruction costs its issuing wave 100-200 cycles; in the MFMA waves' own stream that was
+        //  ~1400 cycles per K step, so it lives in waves that have nothing else to do)
+#pragma unroll
+        for (int s = 0; s < NST - 1; ++s) issue(s);
+        wait_vm<VM_STEP>();
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        int wst = NST - 1;
+        for (int g = 0; g < total; ++g) {
+            issue(wst);                                       // slab g+NST-1 -> the stage freed by the last barrier
+            wst = wst == NST - 1 ? 0 : wst + 1;
+            wait_vm<VM_STEP>();                               // slab g+2 has landed
+            asm volatile("s_barrier" ::: "memory");
+        }
+        wait_vm<0>();
+        return;
+    }
+
+    // ---- consumer state --------------------------------------------------------------------------------------
+    f32x4 acc[MB][NBW];
+#pragma unroll
+    for (int i = 0; i < MB; ++i)
+#pragma unroll
+        for (int j = 0; j < NBW; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int a_off = l15 * ST + 4 * lq;                                        // floats
+    const int b_off = A_BYTES / 4 + (wave * WN + l15) * ST + 4 * lq;
+    f32x4 fa0[MB], fb0[NBW], fa1[MB], fb1[NBW];
+    auto rd = [&](f32x4 (&fa)[MB], f32x4 (&fb)[NBW], int stage, int kk) {
+        const float* S = reinterpret_cast<const float*>(smem + stage * STAGE_BYTES);
+#pragma unroll
+        for (int i = 0; i < MB; ++i) fa[i] = *reinterpret_cast<const f32x4*>(&S[a_off + i * 16 * ST + kk * 16]);
+#pragma unroll
+        for (int j = 0; j < NBW; ++j) fb[j] = *reinterpret_cast<const f32x4*>(&S[b_off + j * 16 * ST + kk * 16]);
+    };
+    auto mm = [&](const f32x4 (&fa)[MB], const f32x4 (&fb)[NBW]) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int i = 0; i < MB; ++i)
+#pragma unroll
+                for (int j = 0; j < NBW; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i][e], fb[j][e], acc[i][j], 0, 0, 0);
+    };
+
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // slabs 0 and 1 landed (loaders waited)
+    unsigned long long t0 = 0, r0 = 0;
+    if (dbg) { t0 = __builtin_amdgcn_s_memtime(); r0 = __builtin_amdgcn_s_memrealtime(); }
+
+    int ks = 0, stage = 0, tile_i = 0;
+    rd(fa0, fb0, 0, 0);
+    for (int g = 0; g < total; ++g) {
+        const int nstage = stage == NST - 1 ? 0 : stage + 1;
+        rd(fa1, fb1, stage, 1);
+        mm(fa0, fb0);
+        if (KK == 4) {
+            rd(fa0, fb0, stage, 2);
+            mm(fa1, fb1);
+            rd(fa1, fb1, stage, 3);
+            mm(fa0, fb0);
+        }
+        if (g + 1 < total) rd(fa0, fb0, nstage, 0);          // next slab's first group: landed before the last barrier
+        mm(fa1, fb1);
+        if (++ks == nk) {
+            ks = 0;
+            // ---- epilogue straight from the accumulators (col = lane&15, row = 4*(lane>>4) + reg); whole tiles
+            //      are stored (the caller pads C by >= 128 rows), so exactly NSTORE store instructions issue
+            const int tile = lid + tile_i * G;
+            ++tile_i;
+            const int m0 = (tile / ntn) * BM, n0 = (tile % ntn) * BN;
+#pragma unroll
+            for (int j = 0; j < NBW; ++j) {
+                const int n = n0 + wave * WN + j * 16 + l15;
+                const float bv = bias_lds[n];
+                float* cp = p.C + (long)(m0 + 4 * lq) * p.ldc + n;
+#pragma unroll
+                for (int i = 0; i < MB; ++i) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float v = acc[i][j][e] + bv;
+                        if (epi == EPI_GELU) v = gelu_fast(v);
+                        cp[(long)(i * 16 + e) * p.ldc] = v;
+                    }
+                    acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+            }
+        }
+        // the loaders have waited for slab g+2 before this barrier; step g+1 prefetches from it
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        stage = nstage;
+    }
+    if (dbg && blockIdx.x == 0 && tid == 0) {                 // diagnostic stamps (gdx_bench_gemm + GDX_GEMM_DEBUG)
+        dbg[0] = __builtin_amdgcn_s_memtime() - t0;
+        dbg[1] = __builtin_amdgcn_s_memrealtime() - r0;
+        dbg[2] = (unsigned long long)total;
+    }
+#endif
+}
+
+unsigned long long* g2_dbg_buf = nullptr;   // set by gdx_bench_gemm when GDX_GEMM_DEBUG is set
+
+template <int MB, int NBW, int BK, int NST>
+constexpr size_t g4_lds_bytes(int N) {
+    constexpr int ROWB = (BK + 8) * 4;
+    constexpr int A_BYTES = (MB * 16 * ROWB + 1023) / 1024 * 1024, W_BYTES = (NBW * 64 * ROWB + 1023) / 1024 * 1024;
+    return (size_t)NST * (A_BYTES + W_BYTES) + (size_t)N * 4;
+}
+
+template <int MB, int NBW, int BK, int NST>
+static hipError_t launch_cfg(const GemmParams& p, int epi, int num_cus, hipStream_t s) {
+    constexpr int BM = MB * 16, BN = NBW * 64;
+    static_assert(g4_lds_bytes<MB, NBW, BK, NST>(2048) <= 160 * 1024, "tile does not fit the 160 KiB LDS");
+    const size_t lds = g4_lds_bytes<MB, NBW, BK, NST>(p.N);
+    static size_t attr_lds = 0;
+    if (lds > attr_lds) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm4_kernel<MB, NBW, BK, NST>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr_lds = lds;
+    }
+    const int ntm = (p.M + BM - 1) / BM, ntn = p.N / BN;
+    const int ntiles = ntm * ntn;
+    const int grid = ntiles < num_cus ? ntiles : num_cus;
+    hipLaunchKernelGGL((gemm4_kernel<MB, NBW, BK, NST>), dim3(grid), dim3(512), lds, s, p, epi, ntn, ntiles,
+                       g2_dbg_buf);
+    return hipGetLastError();
+}
+
+// (MB, NBW, BK, NST): tile = 16*MB x 64*NBW, K slab BK, NST LDS stages (all fit 160 KiB with N <= 2048).
+#define G4_CONFIGS(X) \
+    X(4, 2, 32, 4) X(5, 2, 32, 4) X(6, 2, 32, 4) X(8, 2, 32, 3) X(4, 1, 64, 3) X(5, 1, 64, 3) X(4, 1, 32, 4) X(5, 1, 32, 4) X(8, 1, 32, 4)
+
+static bool g4_valid(int mb, int nbw, int bk, const GemmParams& p) {
+    return p.N % (nbw * 64) == 0 && p.K % bk == 0 && p.N <= 2048;
+}
+
+// Estimated cycles of a tile shape: rounds * (K steps * (MFMA cycles per step + per-step overhead) + per-tile cost).
+static double g4_cost(int mb, int nbw, int bk, int M, int N, int K, int num_cus) {
+    const int BM = mb * 16, BN = nbw * 64;
+    const double tiles = (double)((M + BM - 1) / BM) * (N / BN);
+    const double rounds = (double)(long)((tiles + num_cus - 1) / num_cus);
+    const double mfma = (double)mb * nbw * (bk / 4) * 32.0;          // cycles per K step per wave
+    const double bytes = (double)(BM + BN) * bk * 4.0;               // staged per K step
+    const double mem = bytes / 14.0;                                 // cycles at ~14 B/clk/CU sustained staging
+    const double step = (mfma > mem ? mfma : mem) + 150.0 + (mb + nbw) * (bk / 16) * 8.0;
+    return rounds * ((K / bk) * step + mb * nbw * 4 * 12.0 + 300.0);
+}
+
+int gemm2_num_cus() {
+    static int n = 0;
+    if (!n) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+            n = prop.multiProcessorCount;
+        if (n <= 0) n = 256;
+    }
+    return n;
+}
+
+bool gemm2_supported(int epi, const GemmParams& p) {
+    return (epi == EPI_BIAS || epi == EPI_GELU) && p.K % 32 == 0 && p.N % 64 == 0 && p.N <= 2048 && p.lda % 4 == 0 &&
+           p.ldw % 4 == 0 && (long)(p.M + 128) * p.lda * 4 < (1L << 31) && (long)(p.N + 128) * p.ldw * 4 < (1L << 31);
+}
+
+hipError_t launch_gemm2(int epi, const GemmParams& p, hipStream_t s) {
+    const int num_cus = gemm2_num_cus();
+    int best_mb = 0, best_nbw = 0, best_bk = 0;
+    static int force_mb = -1, force_nbw = -1, force_bk = -1;
+    if (force_mb < 0) {
+        force_mb = force_nbw = force_bk = 0;
+        if (const char* e = getenv("GDX_GEMM_TILE")) sscanf(e, "%d,%d,%d", &force_mb, &force_nbw, &force_bk);
+    }
+    static const bool debug = getenv("GDX_GEMM_DEBUG") != nullptr;
+    double best = 1e30;
+#define X(mb, nbw, bk, nst)                                                                       \
+    if (g4_valid(mb, nbw, bk, p)) {                                                               \
+        double c = g4_cost(mb, nbw, bk, p.M, p.N, p.K, num_cus);                                  \
+        if (force_mb == mb && force_nbw == nbw && force_bk == bk) c = 0.0;                        \
+        if (c < best) { best = c; best_mb = mb; best_nbw = nbw; best_bk = bk; }                   \
+    }
+    G4_CONFIGS(X)
+#undef X
+    if (debug)
+        fprintf(stderr, "[gemm2] M=%d N=%d K=%d epi=%d -> tile %dx%d BK=%d\n", p.M, p.N, p.K, epi, best_mb * 16,
+                best_nbw * 64, best_bk);
+#define X(mb, nbw, bk, nst) \
+    if (best_mb == mb && best_nbw == nbw && best_bk == bk) return launch_cfg<mb, nbw, bk, nst>(p, epi, num_cus, s);
+    G4_CONFIGS(X)
+#undef X
+    return hipErrorInvalidValue;
+}
+
+}  // namespace gdx

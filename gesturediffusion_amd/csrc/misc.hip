@@ -15,22 +15,25 @@ __device__ __forceinline__ float wave_sum(float v) {
 
 // ---------------------------------------------------------------------------------------------
 // LayerNorm over the last dim (post-norm encoder: model/mdm.py:90-96 -> norm1/norm2, eps 1e-5,
-// biased variance).  The residual add is fused into the producing GEMM's epilogue; one wave per
-// row, the row lives in registers, two-pass mean/variance, wave shuffles for the reduce.
-// HBM-bound: 2 * rows * d * 4 bytes.
+// biased variance) with the residual add fused in: out = LN(x + res).  One wave per row, the row
+// lives in registers, two-pass mean/variance, wave shuffles for the reduce.
+// HBM-bound: 3 * rows * d * 4 bytes.
 template <int VPL>   // float4 per lane: d = 256 * VPL
-__global__ __launch_bounds__(256) void layernorm_vec_kernel(const float* __restrict__ x, const float* __restrict__ g,
+__global__ __launch_bounds__(256) void layernorm_vec_kernel(const float* __restrict__ x, const float* __restrict__ res,
+                                                             const float* __restrict__ g,
                                                              const float* __restrict__ bta, float* __restrict__ out,
                                                              int rows, int d) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (row >= rows) return;
     const f32x4* xp = reinterpret_cast<const f32x4*>(x + (long)row * d);
+    const f32x4* rp = reinterpret_cast<const f32x4*>(res + (long)row * d);
     f32x4 v[VPL];
     float s = 0.0f;
 #pragma unroll
     for (int i = 0; i < VPL; ++i) {
         v[i] = xp[lane + 64 * i];
+        if (res) v[i] += rp[lane + 64 * i];
         s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
     }
     const float mean = wave_sum(s) / (float)d;
@@ -57,36 +60,39 @@ __global__ __launch_bounds__(256) void layernorm_vec_kernel(const float* __restr
 }
 
 // generic d (multiple of 32, <= 2048): scalar lane-strided loads
-__global__ __launch_bounds__(256) void layernorm_gen_kernel(const float* __restrict__ x, const float* __restrict__ g,
+__global__ __launch_bounds__(256) void layernorm_gen_kernel(const float* __restrict__ x, const float* __restrict__ res,
+                                                             const float* __restrict__ g,
                                                              const float* __restrict__ bta, float* __restrict__ out,
                                                              int rows, int d) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (row >= rows) return;
     const float* xp = x + (long)row * d;
+    const float* rp = res + (long)row * d;
     float s = 0.0f;
-    for (int e = lane; e < d; e += 64) s += xp[e];
+    for (int e = lane; e < d; e += 64) s += res ? xp[e] + rp[e] : xp[e];
     const float mean = wave_sum(s) / (float)d;
     float q = 0.0f;
     for (int e = lane; e < d; e += 64) {
-        const float c = xp[e] - mean;
+        const float c = (res ? xp[e] + rp[e] : xp[e]) - mean;
         q += c * c;
     }
     const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)d + 1e-5f);
-    for (int e = lane; e < d; e += 64) out[(long)row * d + e] = (xp[e] - mean) * rstd * g[e] + bta[e];
+    for (int e = lane; e < d; e += 64)
+        out[(long)row * d + e] = ((res ? xp[e] + rp[e] : xp[e]) - mean) * rstd * g[e] + bta[e];
 }
 
-hipError_t launch_layernorm(const float* x, const float* gamma, const float* beta, float* out, int rows, int d,
-                            hipStream_t s) {
+hipError_t launch_layernorm(const float* x, const float* res, const float* gamma, const float* beta, float* out,
+                            int rows, int d, hipStream_t s) {
     const dim3 grid((rows + 3) / 4), block(256);
     if (d == 512)
-        hipLaunchKernelGGL(layernorm_vec_kernel<2>, grid, block, 0, s, x, gamma, beta, out, rows, d);
+        hipLaunchKernelGGL(layernorm_vec_kernel<2>, grid, block, 0, s, x, res, gamma, beta, out, rows, d);
     else if (d == 1024)
-        hipLaunchKernelGGL(layernorm_vec_kernel<4>, grid, block, 0, s, x, gamma, beta, out, rows, d);
+        hipLaunchKernelGGL(layernorm_vec_kernel<4>, grid, block, 0, s, x, res, gamma, beta, out, rows, d);
     else if (d == 256)
-        hipLaunchKernelGGL(layernorm_vec_kernel<1>, grid, block, 0, s, x, gamma, beta, out, rows, d);
+        hipLaunchKernelGGL(layernorm_vec_kernel<1>, grid, block, 0, s, x, res, gamma, beta, out, rows, d);
     else
-        hipLaunchKernelGGL(layernorm_gen_kernel, grid, block, 0, s, x, gamma, beta, out, rows, d);
+        hipLaunchKernelGGL(layernorm_gen_kernel, grid, block, 0, s, x, res, gamma, beta, out, rows, d);
     return hipGetLastError();
 }
 

@@ -10,8 +10,8 @@ from gesturediffusion_amd import _lib
 lib = _lib.load()
 torch.cuda.init()
 s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-shapes = [(12608, 1536, 512, 0, "qkv"), (12608, 512, 512, 2, "out-proj"), (12608, 1024, 512, 1, "ffn1+gelu"),
-          (12608, 1024, 512, 0, "ffn1 bias only"), (12608, 512, 1024, 2, "ffn2"), (12800, 1024, 512, 0, "M=12800"),
+shapes = [(12608, 1536, 512, 0, "qkv"), (12608, 512, 512, 0, "out-proj"), (12608, 1024, 512, 1, "ffn1+gelu"),
+          (12608, 1024, 512, 0, "ffn1 bias only"), (12608, 512, 1024, 0, "ffn2"), (12800, 1024, 512, 0, "M=12800"),
           (16384, 1024, 512, 0, "M=16384 (128 tiles x 8)"), (16384, 2048, 4096, 0, "big K"), (8192, 8192, 8192, 0, "8k^3"),
           (25216, 1024, 512, 1, "cfg ffn1")]
 for M, N, K, epi, name in shapes:
