@@ -170,6 +170,9 @@ def main():
         run(args.warmup)
     barrier()
     log(f"timing {args.steps} steps ...")
+    eng0 = inner._get_engine(device)
+    if rank == 0:
+        eng0.profile_begin(512)      # HIP events around the first 512 FFN-1 GEMM launches of the timed region
     t0 = time.perf_counter()
     out = run(args.steps)
     barrier()
@@ -190,8 +193,8 @@ def main():
         flops_step = eng.forward_flops(GDX_CFG if args.cfg else GDX_COND)
         # dominant kernel = the fp32 MFMA GEMM; its north-star instance is FFN linear1 (+bias+GELU):
         # algorithmic FLOPs per launch = 2 * (B*(T+1)) * d * ff, timed with HIP events on the launch stream
-        N, d, ff = B * (T + 1), args.latent_dim, 1024
-        gemm_us = eng.bench_ffn_gemm(50, device)
+        N, d, ff = (2 if args.cfg else 1) * B * (T + 1), args.latent_dim, 1024
+        gemm_us, gemm_launches = eng.profile_end()
         gemm_flops = 2.0 * N * d * ff
         achieved = gemm_flops / (gemm_us * 1e-6) / 1e12
         rec = {
@@ -213,8 +216,9 @@ def main():
             "frame_steps_per_sec": round(world * B * T / (ms_per_step * 1e-3), 1),
             "step_tflops": round(world * flops_step / (ms_per_step * 1e-3) / 1e12, 2),
             "step_frac_of_f32_mfma_peak": round(flops_step / (ms_per_step * 1e-3) / 1e12 / F32_MFMA_PEAK_TFLOPS, 4),
-            "roofline": {"bound": "mfma", "kernel": "gemm_kernel<A_ROWS,B_WEIGHT,OUT_ROWS,EPI_GELU> (FFN linear1, "
-                                                    f"M={N} N={ff} K={d})",
+            "roofline": {"bound": "mfma", "kernel": "gemm4_kernel (gemm2.hip), FFN linear1 + bias + GELU, "
+                                                    f"M={N} N={ff} K={d}; HIP events on the launch stream around "
+                                                    f"{gemm_launches} launches inside the timed loop",
                          "achieved": round(achieved, 2), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / F32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
                          "avg_launch_us": round(gemm_us, 2), "flops_per_launch": gemm_flops},

@@ -73,6 +73,9 @@ struct gdx_model {
     float* x0 = nullptr;              // [2B, J, T]
     float* temb_table = nullptr; int temb_table_rows = 0;
     int64_t* tmap_dev = nullptr;
+    bool prof = false;                // in-situ FFN-1 GEMM timing (gdx_profile_begin / gdx_profile_end)
+    std::vector<hipEvent_t> prof_ev;  // pairs, recorded around each FFN-1 launch while prof is on
+    size_t prof_used = 0;
     bool keep_taps = false;
     std::vector<float*> taps;         // [L+1] x [2B*S*d] when keep_taps
 };
@@ -155,6 +158,7 @@ extern "C" int gdx_destroy(gdx_handle_t h) {
     if (!h) return 0;
     free_pool(h->allocs);
     free_pool(h->ws_allocs);
+    for (hipEvent_t e : h->prof_ev) (void)hipEventDestroy(e);
     delete h;
     return 0;
 }
@@ -412,7 +416,13 @@ static int forward_core(gdx_model* h, const float* x, const float* temb, int tst
         if (gemm(A_ROWS, B_WEIGHT, OUT_ROWS, EPI_BIAS, p, s)) return -1;
         HIPCHK(launch_layernorm(h->tmp, h->xa, ly.g1, ly.b1, h->xb, N, d, s));
         p = GemmParams{h->xb, d, ly.ff1.w, ly.ff1.kpad, ly.ff1.bias, nullptr, 0, nullptr, 0, h->ffb, h->ff, N, h->ff, d, T, B};
+        const bool stamp = h->prof && h->prof_used + 2 <= h->prof_ev.size();
+        if (stamp) HIPCHK(hipEventRecord(h->prof_ev[h->prof_used], s));
         if (gemm(A_ROWS, B_WEIGHT, OUT_ROWS, EPI_GELU, p, s)) return -1;
+        if (stamp) {
+            HIPCHK(hipEventRecord(h->prof_ev[h->prof_used + 1], s));
+            h->prof_used += 2;
+        }
         p = GemmParams{h->ffb, h->ff, ly.ff2.w, ly.ff2.kpad, ly.ff2.bias, nullptr, 0, nullptr, 0, h->tmp, d, N, d, h->ff, T, B};
         if (gemm(A_ROWS, B_WEIGHT, OUT_ROWS, EPI_BIAS, p, s)) return -1;
         HIPCHK(launch_layernorm(h->tmp, h->xb, ly.g2, ly.b2, h->xa, N, d, s));
@@ -505,6 +515,33 @@ extern "C" int gdx_sample_loop(gdx_handle_t h, const gdx_loop_args_t* a, void* s
             ++dump_i;
         }
     }
+    return 0;
+}
+
+extern "C" int gdx_profile_begin(gdx_handle_t h, int32_t max_launches) {
+    if (!h || max_launches <= 0) return fail("gdx_profile_begin: bad argument");
+    while (h->prof_ev.size() < 2 * (size_t)max_launches) {
+        hipEvent_t e;
+        HIPCHK(hipEventCreate(&e));
+        h->prof_ev.push_back(e);
+    }
+    h->prof_used = 0;
+    h->prof = true;
+    return 0;
+}
+
+extern "C" int gdx_profile_end(gdx_handle_t h, float* avg_us, int32_t* launches) {
+    if (!h || !avg_us || !launches) return fail("gdx_profile_end: null argument");
+    h->prof = false;
+    double sum = 0.0;
+    for (size_t i = 0; i + 1 < h->prof_used; i += 2) {
+        HIPCHK(hipEventSynchronize(h->prof_ev[i + 1]));
+        float ms = 0.f;
+        HIPCHK(hipEventElapsedTime(&ms, h->prof_ev[i], h->prof_ev[i + 1]));
+        sum += ms;
+    }
+    *launches = (int32_t)(h->prof_used / 2);
+    *avg_us = *launches ? (float)(sum * 1000.0 / *launches) : 0.f;
     return 0;
 }
 

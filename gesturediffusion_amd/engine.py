@@ -134,6 +134,14 @@ class Engine:
         _lib.check(self.lib.gdx_forward_flops(self.handle, mode, C.byref(f)), self.lib)
         return f.value
 
+    def profile_begin(self, max_launches):
+        _lib.check(self.lib.gdx_profile_begin(self.handle, max_launches), self.lib)
+
+    def profile_end(self):
+        us, n = C.c_float(), C.c_int32()
+        _lib.check(self.lib.gdx_profile_end(self.handle, C.byref(us), C.byref(n)), self.lib)
+        return us.value, n.value
+
     def bench_ffn_gemm(self, iters, device):
         us = C.c_float()
         _lib.check(self.lib.gdx_bench_ffn_gemm(self.handle, iters, C.byref(us), _stream(device)), self.lib)

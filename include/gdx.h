@@ -169,6 +169,11 @@ int gdx_sample_loop(gdx_handle_t h, const gdx_loop_args_t* a, void* stream);
 /* Time `iters` launches of the FFN-1 GEMM (bias+GELU epilogue) of layer 0 on the current
  * workspace shape with HIP events on `stream`; returns average microseconds per launch. */
 int gdx_bench_ffn_gemm(gdx_handle_t h, int32_t iters, float* avg_us, void* stream);
+/* In-situ timing of the FFN linear1 GEMM launches of subsequent forwards / loops: HIP events recorded on the
+ * launch stream around each of the next (at most `max_launches`) launches; gdx_profile_end synchronises on them
+ * and returns their average duration. */
+int gdx_profile_begin(gdx_handle_t h, int32_t max_launches);
+int gdx_profile_end(gdx_handle_t h, float* avg_us, int32_t* launches);
 /* Time `iters` launches of a stand-alone C[M,N] = A[M,K] W[N,K]^T GEMM with epilogue `epi`
  * (0 bias, 1 bias+GELU, 2 bias+residual) on scratch buffers filled with N(0,1). */
 int gdx_bench_gemm(int32_t M, int32_t N, int32_t K, int32_t epi, int32_t iters, float* avg_us, void* stream);
