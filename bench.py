@@ -196,6 +196,11 @@ def main():
         N, d, ff = (2 if args.cfg else 1) * B * (T + 1), args.latent_dim, 1024
         gemm_us, gemm_launches = eng.profile_end()
         gemm_flops = 2.0 * N * d * ff
+        traffic, traffic_src = None, None
+        pmc = os.path.join(REPO, "profiles", "r01b_pmc_ffn1_traffic.json")
+        if os.path.exists(pmc) and not args.cfg and (B, T, d, args.arch) == (64, 196, 512, "mdm_old"):
+            traffic = json.load(open(pmc))["hbm_bytes_per_launch"]     # PMC passes cannot run inside this process
+            traffic_src = "profiles/r01b_pmc_ffn1_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this bench)"
         achieved = gemm_flops / (gemm_us * 1e-6) / 1e12
         rec = {
             "metric": "denoised motion frames/sec (1000-step p_sample_loop, B=64, T=196, d=512)",
@@ -220,7 +225,8 @@ def main():
                                                     f"M={N} N={ff} K={d}; HIP events on the launch stream around "
                                                     f"{gemm_launches} launches inside the timed loop",
                          "achieved": round(achieved, 2), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved / F32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                         "frac": round(achieved / F32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
+                         "traffic_source": traffic_src,
                          "avg_launch_us": round(gemm_us, 2), "flops_per_launch": gemm_flops},
         }
         if not args.no_cpu_baseline:
