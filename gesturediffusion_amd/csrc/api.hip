@@ -308,7 +308,12 @@ extern "C" int gdx_prepare(gdx_handle_t h, int32_t batch, int32_t frames) {
     h->B = batch; h->T = frames; h->S = frames + 1; h->cond_set = false;
     // +128 rows: the persistent GEMM reads / stores whole tiles past the last logical row (gemm2.hip)
     const size_t B2 = 2 * (size_t)batch, N = B2 * h->S + 128, d = h->d;
-    auto A = [&](float** p, size_t n) { return dev_alloc(h->ws_allocs, (void**)p, n * sizeof(float)); };
+    // zero-filled: the padding rows are read by whole-tile GEMMs / K-V tiles and must stay finite
+    auto A = [&](float** p, size_t n) {
+        if (dev_alloc(h->ws_allocs, (void**)p, n * sizeof(float))) return -1;
+        if (hipMemset(*p, 0, n * sizeof(float)) != hipSuccess) return fail("gdx_prepare: hipMemset failed");
+        return 0;
+    };
     if (A(&h->xa, N * d) || A(&h->xb, N * d) || A(&h->qkv, N * 3 * d) || A(&h->ctx, N * d) || A(&h->tmp, N * d) ||
         A(&h->ffb, N * h->ff) || A(&h->addend, N * d) || A(&h->seed_cat, B2 * d) || A(&h->temb_in, B2 * d) ||
         A(&h->temb_h, B2 * d) || A(&h->temb, B2 * d) || A(&h->coa, B2 * d) || A(&h->c2, B2 * d) ||
@@ -410,7 +415,11 @@ static int forward_core(gdx_model* h, const float* x, const float* temb, int tst
         const Layer& ly = h->layers[l];
         p = GemmParams{h->xa, d, ly.qkv.w, ly.qkv.kpad, ly.qkv.bias, nullptr, 0, nullptr, 0, h->qkv, 3 * d, N, 3 * d, d, T, B};
         if (gemm(A_ROWS, B_WEIGHT, OUT_ROWS, EPI_BIAS, p, s)) return -1;
-        HIPCHK(launch_attention(h->qkv, h->ctx, Beff, S, h->H, d, s));
+        static const bool attn_v1 = getenv("GDX_ATTN_V1") != nullptr;   // A/B switch for measurements
+        if (!attn_v1 && attention2_supported(S, h->H, d))
+            HIPCHK(launch_attention2(h->qkv, h->ctx, Beff, S, h->H, d, s));
+        else
+            HIPCHK(launch_attention(h->qkv, h->ctx, Beff, S, h->H, d, s));
         // x = LN1(x + out_proj(ctx)): the residual add rides in the LayerNorm kernel (see gemm2.hip)
         p = GemmParams{h->ctx, d, ly.out.w, ly.out.kpad, ly.out.bias, nullptr, 0, nullptr, 0, h->tmp, d, N, d, d, T, B};
         if (gemm(A_ROWS, B_WEIGHT, OUT_ROWS, EPI_BIAS, p, s)) return -1;
@@ -644,6 +653,40 @@ extern "C" int gdx_bench_gemm(int32_t M, int32_t N, int32_t K, int32_t epi, int3
                         h[0], h[1] / 100.0, h[2], (double)h[0] / h[2], h[1] ? (double)h[0] / (h[1] * 10.0) : 0.0);
         }
     }
+    free_pool(pool);
+    return 0;
+}
+
+// Stand-alone attention timing on scratch buffers (measurement helper for tools/attn_one.py).
+extern "C" int gdx_bench_attention(int32_t B, int32_t S, int32_t H, int32_t d, int32_t version, int32_t iters,
+                                   float* avg_us, void* stream) {
+    if (!avg_us || B <= 0 || S <= 0 || H <= 0 || d <= 0 || d % H || iters <= 0) return fail("gdx_bench_attention: bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    float *qkv = nullptr, *ctx = nullptr;
+    std::vector<void*> pool;
+    const size_t rows = (size_t)B * S + 128;
+    if (dev_alloc(pool, (void**)&qkv, sizeof(float) * rows * 3 * d) || dev_alloc(pool, (void**)&ctx, sizeof(float) * rows * d)) {
+        free_pool(pool);
+        return -1;
+    }
+    HIPCHK(gdx_randn(qkv, 1, (int64_t)rows * 3 * d, 5, 0, 0, stream) ? hipErrorUnknown : hipSuccess);
+    auto run = [&]() -> hipError_t {
+        if (version == 2 && attention2_supported(S, H, d)) return launch_attention2(qkv, ctx, B, S, H, d, s);
+        return launch_attention(qkv, ctx, B, S, H, d, s);
+    };
+    hipEvent_t e0, e1;
+    HIPCHK(hipEventCreate(&e0));
+    HIPCHK(hipEventCreate(&e1));
+    for (int i = 0; i < 3; ++i) HIPCHK(run());
+    HIPCHK(hipEventRecord(e0, s));
+    for (int i = 0; i < iters; ++i) HIPCHK(run());
+    HIPCHK(hipEventRecord(e1, s));
+    HIPCHK(hipEventSynchronize(e1));
+    float ms = 0.f;
+    HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+    *avg_us = ms * 1000.0f / (float)iters;
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
     free_pool(pool);
     return 0;
 }

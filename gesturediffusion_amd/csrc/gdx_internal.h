@@ -43,6 +43,10 @@ hipError_t launch_gemm2(int epi, const GemmParams& p, hipStream_t s);
 // qkv [B*S][3d] (q | k | v, heads contiguous inside each), ctx [B*S][d]
 hipError_t launch_attention(const float* qkv, float* ctx, int B, int S, int H, int d, hipStream_t s);
 
+// 16-row-granular variant for head_dim 64/128 and <= 256 tokens (attention2.hip)
+bool attention2_supported(int S, int H, int d);
+hipError_t launch_attention2(const float* qkv, float* ctx, int B, int S, int H, int d, hipStream_t s);
+
 // ---- misc (misc.hip) ---------------------------------------------------------------------
 // out = LayerNorm(x + res) (res may be nullptr)
 hipError_t launch_layernorm(const float* x, const float* res, const float* gamma, const float* beta, float* out,

@@ -255,6 +255,25 @@ def test_real_shapes_vs_reference_golden(name, arch, J, dm):
         assert rel_err(r.cpu(), g["c1_v2.ddim10"]) < LOOP_TOL
 
 
+@pytest.mark.parametrize("arch,dm,H,T,B", [("mdm_old", 256, 4, 37, 3), ("mdm", 256, 4, 40, 2), ("mdm_old", 512, 4, 15, 5),
+                                            ("mdm_old", 128, 2, 250, 1), ("mdm", 512, 8, 30, 2)])
+def test_forward_vs_oracle_odd_shapes(arch, dm, H, T, B):
+    """Shapes outside the fixtures: head_dim 64 (attention2's second instantiation), sequences that are
+    not multiples of the 16/32-token blocks, a single sample, 8 heads, K = 263+ tails -- against the CPU oracle."""
+    from gesturediffusion_amd.utils.init import init_state_dict, synthetic_inputs
+    from oracle import mdm_forward as omf
+    cfg = dict(arch=arch, njoints=37, nfeats=1, latent_dim=dm, ff_size=192, num_layers=2, num_heads=H, seed_poses=10)
+    sd = init_state_dict(cfg, seed=5, perturb=True)
+    m = build_model(arch, cfg, sd)
+    d = dev()
+    x, seedp, mfcc = synthetic_inputs(cfg, B, T, seed=11)
+    t = (torch.arange(B) * 97 + 3) % 1000
+    out = m(x.to(d), t.to(d), {"seed": seedp.to(d), "mfcc": mfcc.to(d)})
+    with torch.no_grad():
+        want = omf.forward(sd, cfg, x, t, {"seed": seedp, "mfcc": mfcc})
+    assert rel_err(out.cpu(), want) < FWD_TOL
+
+
 def test_cfg_forward_matches_two_pass_blend():
     from gesturediffusion_amd.model.cfg_sampler import ClassifierFreeSampleModel
     from gesturediffusion_amd.utils.init import init_state_dict, synthetic_inputs
