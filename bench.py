@@ -229,7 +229,7 @@ def main():
                          "traffic_source": traffic_src,
                          "avg_launch_us": round(gemm_us, 2), "flops_per_launch": gemm_flops},
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:
             rec["cpu_baseline"] = cpu_baseline(cfg, sd, B, T, seedp, mfcc, args.cpu_steps)
             rec["gpu_over_cpu"] = round(frames_per_sec / world / rec["cpu_baseline"]["value"], 1)
         print(json.dumps(rec), flush=True)

@@ -268,7 +268,7 @@ static hipError_t launch_cfg(const GemmParams& p, int epi, int num_cus, hipStrea
 
 // (MB, NBW, BK, NST): tile = 16*MB x 64*NBW, K slab BK, NST LDS stages (all fit 160 KiB with N <= 2048).
 #define G4_CONFIGS(X) \
-    X(4, 2, 32, 4) X(5, 2, 32, 4) X(6, 2, 32, 4) X(8, 2, 32, 3) X(4, 1, 64, 3) X(5, 1, 64, 3) X(4, 1, 32, 4) X(5, 1, 32, 4) X(8, 1, 32, 4)
+    X(4, 2, 32, 4) X(5, 2, 32, 4) X(6, 2, 32, 4) X(8, 2, 32, 3) X(5, 3, 32, 3) X(4, 3, 32, 3) X(4, 1, 64, 3) X(5, 1, 64, 3) X(4, 1, 32, 4) X(5, 1, 32, 4) X(8, 1, 32, 4)
 
 static bool g4_valid(int mb, int nbw, int bk, const GemmParams& p) {
     return p.N % (nbw * 64) == 0 && p.K % bk == 0 && p.N <= 2048;

@@ -134,7 +134,7 @@ class GaussianDiffusion:
         """[num_timesteps, 8] fp32 rows consumed by gdx_sampler_update.  Every entry is rounded
         exactly like the reference: fp64 table -> .float() (gaussian_diffusion.py:1595-1608), then
         fp32 torch ops in the reference's order."""
-        key = (kind, str(device), float(eta))
+        key = (kind, str(device), eta if eta == "reverse" else float(eta))
         if key in self._coef_cache:
             return self._coef_cache[key]
         self._check_supported()
@@ -149,12 +149,17 @@ class GaussianDiffusion:
             c[:, 2] = nz * th.exp(0.5 * f32(logvar))
         else:
             ab, abp = f32(self.alphas_cumprod), f32(self.alphas_cumprod_prev)
-            sigma = eta * th.sqrt((1 - abp) / (1 - ab)) * th.sqrt(1 - ab / abp)
+            sigma = (0.0 if eta == "reverse" else eta) * th.sqrt((1 - abp) / (1 - ab)) * th.sqrt(1 - ab / abp)
             c[:, 0] = f32(self.sqrt_recip_alphas_cumprod)
             c[:, 1] = f32(self.sqrt_recipm1_alphas_cumprod)
             c[:, 2] = th.sqrt(abp)
             c[:, 3] = th.sqrt(1 - abp - sigma ** 2)
             c[:, 4] = nz * sigma
+        if kind == GDX_SAMPLER_DDIM and eta == "reverse":
+            abn = f32(self.alphas_cumprod_next)          # ddim_reverse_sample (:841-877): same kernel, next-alpha rows
+            c[:, 2] = th.sqrt(abn)
+            c[:, 3] = th.sqrt(1 - abn)
+            c[:, 4] = 0.0
         c[:, 5] = f32(self.sqrt_alphas_cumprod)
         c[:, 6] = f32(self.sqrt_one_minus_alphas_cumprod)
         c = c.to(device)
@@ -230,6 +235,13 @@ class GaussianDiffusion:
     def ddim_sample(self, model, x, t, clip_denoised=True, denoised_fn=None, cond_fn=None, model_kwargs=None,
                     eta=0.0):
         return self._step(GDX_SAMPLER_DDIM, model, x, t, clip_denoised, denoised_fn, cond_fn, model_kwargs, eta=eta)
+
+    def ddim_reverse_sample(self, model, x, t, clip_denoised=True, denoised_fn=None, model_kwargs=None, eta=0.0):
+        """Sample x_{t+1} with the DDIM reverse ODE (reference :841-877); the fused update kernel with the
+        next-alpha coefficient rows and zero noise weight."""
+        assert eta == 0.0, "Reverse ODE only for deterministic path"
+        return self._step(GDX_SAMPLER_DDIM, model, x, t, clip_denoised, denoised_fn, None, model_kwargs, eta="reverse",
+                          noise=th.zeros_like(x))
 
     def p_mean_variance(self, model, x, t, clip_denoised=True, denoised_fn=None, model_kwargs=None):
         """Dict API of the reference (:277-388).  mean = update with zero noise; the variance

@@ -49,6 +49,13 @@ def ddim_step(tab, x0, x, t, noise, eta=0.0):
     return mean + nonzero * sigma * noise
 
 
+def ddim_reverse_step(tab, x0, x, t):
+    """reference gaussian_diffusion.py:841-877 (deterministic x_t -> x_{t+1})."""
+    eps = (extract(tab.sqrt_recip_alphas_cumprod, t) * x - x0) / extract(tab.sqrt_recipm1_alphas_cumprod, t)
+    ab_next = extract(tab.alphas_cumprod_next, t)
+    return x0 * torch.sqrt(ab_next) + torch.sqrt(1 - ab_next) * eps
+
+
 def sample_loop(model_fn, tab, tmap, shape, tape, y, kind="p", eta=0.0, skip_timesteps=0,
                 init_image=None, const_noise=False, dump_steps=None):
     """Drive `model_fn(x, mapped_t, y) -> x0` through the whole reverse process.

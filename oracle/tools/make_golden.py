@@ -239,6 +239,14 @@ def gen_loops_tiny(mods, out):
         yin = dict(y, inpainting_mask=mask, inpainted_motion=motion)
         d["p20_inpaint"] = run("p", [20], m, yin).numpy()
         d["p20_cfg_inpaint"] = run("p", [20], cfgm, dict(yin, scale=scale)).numpy()
+        # ddim_reverse_sample (gaussian_diffusion.py:841-877): three deterministic steps x_t -> x_{t+1}
+        df = make_diffusion(gd, rs, "ddim10")
+        xr = tape[0].clone()
+        with torch.no_grad():
+            for ti in (0, 1, 2):
+                xr = df.ddim_reverse_sample(m, xr, torch.tensor([ti] * B), clip_denoised=False,
+                                            model_kwargs={"y": y})["sample"]
+        d["ddim10_reverse3"] = xr.numpy()
         np.savez_compressed(os.path.join(out, f"loops_{arch}_tiny.npz"), **d)
 
 

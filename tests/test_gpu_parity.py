@@ -224,6 +224,20 @@ def test_loops_tiny_vs_reference_golden(arch, name, fused):
     assert rel_err(r.cpu(), g[name]) < LOOP_TOL, name
 
 
+@pytest.mark.parametrize("arch", ["mdm", "mdm_old"])
+def test_ddim_reverse_vs_reference_golden(arch):
+    g = load_golden(f"loops_{arch}_tiny.npz")
+    d = dev()
+    m = build_model(arch, TINY, weights_from(g))
+    y = {"seed": torch.from_numpy(g["seed"]).to(d), "mfcc": torch.from_numpy(g["mfcc"]).to(d)}
+    df = _diffusion("ddim10")
+    x = torch.from_numpy(g["tape"])[0].to(d)
+    for ti in (0, 1, 2):
+        x = df.ddim_reverse_sample(m, x, torch.full((x.shape[0],), ti, device=d), clip_denoised=False,
+                                   model_kwargs={"y": y})["sample"]
+    assert rel_err(x.cpu(), g["ddim10_reverse3"]) < LOOP_TOL
+
+
 def _real_cfg(arch, J, d):
     return dict(arch=arch, njoints=J, nfeats=1, latent_dim=d, ff_size=1024, num_layers=8, num_heads=4, seed_poses=10)
 

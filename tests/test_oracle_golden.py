@@ -127,6 +127,22 @@ def test_loops_tiny(arch, name):
     assert rel_err(r, g[name]) < 2e-5, name
 
 
+@pytest.mark.parametrize("arch", ["mdm", "mdm_old"])
+def test_ddim_reverse_tiny(arch):
+    g = load_golden(f"loops_{arch}_tiny.npz")
+    p = weights_from(g)
+    cfg = dict(TINY, arch=arch)
+    y = {"seed": torch.from_numpy(g["seed"]), "mfcc": torch.from_numpy(g["mfcc"])}
+    tab, tmap = osch.make_tables("cosine", 1000, "ddim10")
+    x = torch.from_numpy(g["tape"])[0]
+    mapt = torch.tensor(tmap)
+    with torch.no_grad():
+        for ti in (0, 1, 2):
+            t = torch.tensor([ti] * x.shape[0])
+            x = osamp.ddim_reverse_step(tab, omf.forward(p, cfg, x, mapt[t], y), x, t)
+    assert rel_err(x, g["ddim10_reverse3"]) < 2e-5
+
+
 def test_sampler_update_bit_exact():
     """Given the same x0 / x / noise the closed-form update is bit-identical to the
     reference's (checked through a 1-step loop whose model returns a fixed tensor)."""
