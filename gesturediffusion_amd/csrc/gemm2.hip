@@ -93,8 +93,10 @@ __global__ __launch_bounds__(512, 1) void gemm4_kernel(const GemmParams p, const
     const int total = my_tiles * nk;
     if (total == 0) return;
 
-    // bias -> LDS once (the only ordinary global loads of the kernel, before any DMA is in flight)
-    for (int i = tid; i < p.N; i += 512) bias_lds[i] = p.bias ? p.bias[i] : 0.0f;
+    // bias -> LDS once, by the consumer waves only (idle until the first slab lands anyway); the loader waves go
+    // straight to their DMA so the first slab's latency is not stacked behind the bias load
+    if (wave < 4)
+        for (int i = tid; i < p.N; i += 256) bias_lds[i] = p.bias ? p.bias[i] : 0.0f;
 
     // ---- DMA set-up: descriptors (wave-uniform) and tile-independent per-lane offsets ------------------------
     const auto rsrcA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.A), (short)0, 0x7ffffff0, 0x00020000);

@@ -38,13 +38,16 @@ def init_from_env(backend=None):
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     use_cuda = th.cuda.is_available()
+    if use_cuda and os.environ.get("GDX_SINGLE_GPU_RANKS"):   # rehearsal: several ranks share GPU 0 (gloo backend)
+        local = 0
     device = th.device(f"cuda:{local}") if use_cuda else th.device("cpu")
     if use_cuda:
         th.cuda.set_device(device)
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        dist.init_process_group(backend or ("nccl" if use_cuda else "gloo"), rank=rank, world_size=world)
+        backend = backend or os.environ.get("GDX_DIST_BACKEND") or ("nccl" if use_cuda else "gloo")
+        dist.init_process_group(backend, rank=rank, world_size=world)
     setup_dist(local if use_cuda else -1)
     return rank, world, device
 
