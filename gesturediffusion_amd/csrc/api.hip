@@ -71,6 +71,8 @@ struct gdx_model {
     float *emb_pose = nullptr, *xseq = nullptr, *addend = nullptr;
     float *seed_cat = nullptr, *temb_in = nullptr, *temb_h = nullptr, *temb = nullptr, *coa = nullptr, *c2 = nullptr;
     float* x0 = nullptr;              // [2B, J, T]
+    float *xt = nullptr, *xc = nullptr, *x0t = nullptr;   // token-major pose in / compacted last layer / token-major x0
+    int ldo = 0;                      // row stride of x0t = J rounded up to 64
     float* temb_table = nullptr; int temb_table_rows = 0;
     int64_t* tmap_dev = nullptr;
     bool prof = false;                // in-situ FFN-1 GEMM timing (gdx_profile_begin / gdx_profile_end)
@@ -316,9 +318,12 @@ extern "C" int gdx_prepare(gdx_handle_t h, int32_t batch, int32_t frames) {
     };
     if (A(&h->xa, N * d) || A(&h->xb, N * d) || A(&h->qkv, N * 3 * d) || A(&h->ctx, N * d) || A(&h->tmp, N * d) ||
         A(&h->ffb, N * h->ff) || A(&h->addend, N * d) || A(&h->seed_cat, B2 * d) || A(&h->temb_in, B2 * d) ||
-        A(&h->temb_h, B2 * d) || A(&h->temb, B2 * d) || A(&h->coa, B2 * d) || A(&h->c2, B2 * d) ||
+        A(&h->temb_h, B2 * d) || A(&h->temb, B2 * d) || A(&h->coa, B2 * d) || A(&h->c2, (B2 + 1) * d) ||
         A(&h->x0, B2 * h->J * (size_t)frames))
         return -1;
+    h->ldo = round_up(h->J, 64);
+    const size_t NT = B2 * frames + 128;
+    if (A(&h->xt, NT * round_up(h->J, 32)) || A(&h->xc, NT * d) || A(&h->x0t, NT * h->ldo)) return -1;
     if (h->cfg.arch == GDX_ARCH_MDM && (A(&h->emb_pose, (B2 * frames + 128) * d) || A(&h->xseq, (B2 * frames + 128) * d))) return -1;
     if (h->keep_taps) {
         h->taps.resize(h->L + 1);
@@ -378,10 +383,20 @@ extern "C" int gdx_set_condition(gdx_handle_t h, const float* seed, const float*
 static int gemm(int am, int bm, int om, int ep, const GemmParams& p, hipStream_t s) {
     static const bool force_v1 = getenv("GDX_GEMM_V1") != nullptr;   // A/B switch for measurements
     hipError_t e;
-    if (!force_v1 && am == A_ROWS && bm == B_WEIGHT && om == OUT_ROWS && gemm2_supported(ep, p))
-        e = launch_gemm2(ep, p, s);
-    else
-        e = launch_gemm(am, bm, om, ep, p, s);
+    if (!force_v1 && am == A_ROWS && bm == B_WEIGHT) {
+        // persistent kernel: residual / per-sample-vector terms are selected by the pointers, not by the mode
+        GemmParams q = p;
+        int ep2 = ep;
+        if (ep == EPI_BIAS || ep == EPI_GELU) { q.R = nullptr; q.V = nullptr; }
+        if (ep == EPI_RES) { q.V = nullptr; ep2 = EPI_BIAS; }
+        if (ep == EPI_RES_VEC) { q.bias = nullptr; ep2 = EPI_BIAS; }
+        if (gemm2_supported(om, ep2, q)) {
+            e = launch_gemm2(om, ep2, q, s);
+            if (e != hipSuccess) return fail(std::string("launch_gemm2: ") + hipGetErrorString(e));
+            return 0;
+        }
+    }
+    e = launch_gemm(am, bm, om, ep, p, s);
     if (e != hipSuccess) return fail(std::string("launch_gemm: ") + hipGetErrorString(e));
     return 0;
 }
@@ -395,14 +410,18 @@ static int forward_core(gdx_model* h, const float* x, const float* temb, int tst
     const float* seed_emb = mode == GDX_UNCOND ? h->seed_cat + (size_t)B * d : h->seed_cat;
     const int N = Beff * S;
     GemmParams p;
+    // pose tensor [B, J, 1, T] -> token-major [Beff*T, Jpad] once (CFG: the same x feeds both halves)
+    const int Jp = h->in_x.kpad;
+    HIPCHK(launch_transpose_in(x, h->xt, Beff, B, J, T, Jp, s));
     if (h->cfg.arch == GDX_ARCH_MDM_OLD) {
         HIPCHK(launch_token0(temb, tstride, seed_emb, h->pe, h->xa, nullptr, Beff, B, S, d, s));
-        p = GemmParams{x, 0, h->in_x.w, h->in_x.kpad, nullptr, h->addend, d, nullptr, 0, h->xa, d, Beff * T, d, J, T, B};
-        if (gemm(A_POSE, B_WEIGHT, OUT_TOKROWS, EPI_RES, p, s)) return -1;
+        // frames -> rows (b, t+1) of the encoder input, + hoisted MFCC/bias/PE term      (model/mdm_old.py:104-112)
+        p = GemmParams{h->xt, Jp, h->in_x.w, h->in_x.kpad, nullptr, h->addend, d, nullptr, 0, h->xa, d, Beff * T, d, Jp, T, B};
+        if (gemm(A_ROWS, B_WEIGHT, OUT_TOKROWS, EPI_RES, p, s)) return -1;
     } else {
         HIPCHK(launch_token0(temb, tstride, seed_emb, nullptr, h->xa, h->coa, Beff, B, S, d, s));
-        p = GemmParams{x, 0, h->in_x.w, h->in_x.kpad, h->in_x.bias, nullptr, 0, nullptr, 0, h->emb_pose, d, Beff * T, d, J, T, B};
-        if (gemm(A_POSE, B_WEIGHT, OUT_ROWS, EPI_BIAS, p, s)) return -1;
+        p = GemmParams{h->xt, Jp, h->in_x.w, h->in_x.kpad, h->in_x.bias, nullptr, 0, nullptr, 0, h->emb_pose, d, Beff * T, d, Jp, T, B};
+        if (gemm(A_ROWS, B_WEIGHT, OUT_ROWS, EPI_BIAS, p, s)) return -1;
         HIPCHK(launch_small_linear(h->coa, d, h->proj_coa.w, h->proj_coa.kpad, nullptr, h->c2, d, Beff, d, d, 0, s));
         p = GemmParams{h->emb_pose, d, h->proj_pose.w, h->proj_pose.kpad, nullptr, h->addend, d, h->c2, d, h->xseq, d, Beff * T, d, d, T, B};
         if (gemm(A_ROWS, B_WEIGHT, OUT_ROWS, EPI_RES_VEC, p, s)) return -1;
@@ -423,7 +442,7 @@ static int forward_core(gdx_model* h, const float* x, const float* temb, int tst
         // x = LN1(x + out_proj(ctx)): the residual add rides in the LayerNorm kernel (see gemm2.hip)
         p = GemmParams{h->ctx, d, ly.out.w, ly.out.kpad, ly.out.bias, nullptr, 0, nullptr, 0, h->tmp, d, N, d, d, T, B};
         if (gemm(A_ROWS, B_WEIGHT, OUT_ROWS, EPI_BIAS, p, s)) return -1;
-        HIPCHK(launch_layernorm(h->tmp, h->xa, ly.g1, ly.b1, h->xb, N, d, s));
+        HIPCHK(launch_layernorm(h->tmp, h->xa, ly.g1, ly.b1, h->xb, N, d, 0, s));
         p = GemmParams{h->xb, d, ly.ff1.w, ly.ff1.kpad, ly.ff1.bias, nullptr, 0, nullptr, 0, h->ffb, h->ff, N, h->ff, d, T, B};
         const bool stamp = h->prof && h->prof_used + 2 <= h->prof_ev.size();
         if (stamp) HIPCHK(hipEventRecord(h->prof_ev[h->prof_used], s));
@@ -434,13 +453,17 @@ static int forward_core(gdx_model* h, const float* x, const float* temb, int tst
         }
         p = GemmParams{h->ffb, h->ff, ly.ff2.w, ly.ff2.kpad, ly.ff2.bias, nullptr, 0, nullptr, 0, h->tmp, d, N, d, h->ff, T, B};
         if (gemm(A_ROWS, B_WEIGHT, OUT_ROWS, EPI_BIAS, p, s)) return -1;
-        HIPCHK(launch_layernorm(h->tmp, h->xb, ly.g2, ly.b2, h->xa, N, d, s));
+        const bool last = l + 1 == h->L;
+        // the last layer's output is only needed without token 0 (model/mdm.py:219): write it compacted [Beff*T, d]
+        if (!last || h->keep_taps) HIPCHK(launch_layernorm(h->tmp, h->xb, ly.g2, ly.b2, h->xa, N, d, 0, s));
+        if (last) HIPCHK(launch_layernorm(h->tmp, h->xb, ly.g2, ly.b2, h->xc, N, d, S, s));
         if (h->keep_taps)
             HIPCHK(hipMemcpyAsync(h->taps[l + 1], h->xa, sizeof(float) * (size_t)N * d, hipMemcpyDeviceToDevice, s));
     }
-    // OutputProcess, swapped: x0[b, j, t] = sum_k W_out[j][k] * h[b, t+1, k] + b_out[j]   (model/mdm.py:372-380)
-    p = GemmParams{h->outp.w, h->outp.kpad, h->xa, d, h->outp.bias, nullptr, 0, nullptr, 0, x0_out, 0, J, Beff * T, d, T, B};
-    if (gemm(A_ROWS, B_TOKENS, OUT_POSE, EPI_BIAS, p, s)) return -1;
+    // OutputProcess (model/mdm.py:372-380): token-major GEMM, then the permute back to [B, J, 1, T]
+    p = GemmParams{h->xc, d, h->outp.w, h->outp.kpad, h->outp.bias, nullptr, 0, nullptr, 0, h->x0t, h->ldo, Beff * T, h->ldo, d, T, B};
+    if (gemm(A_ROWS, B_WEIGHT, OUT_ROWS, EPI_BIAS, p, s)) return -1;
+    HIPCHK(launch_transpose_out(h->x0t, x0_out, Beff, J, T, h->ldo, s));
     return 0;
 }
 

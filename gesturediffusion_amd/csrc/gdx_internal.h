@@ -36,8 +36,8 @@ hipError_t gemm_init();   // raises the dynamic-LDS limit of every instantiation
 hipError_t launch_gemm(int amode, int bmode, int omode, int epi, const GemmParams& p, hipStream_t s);
 
 // persistent wave-specialised variant for A_ROWS x B_WEIGHT -> OUT_ROWS (gemm2.hip)
-bool gemm2_supported(int epi, const GemmParams& p);
-hipError_t launch_gemm2(int epi, const GemmParams& p, hipStream_t s);
+bool gemm2_supported(int omode, int epi, const GemmParams& p);
+hipError_t launch_gemm2(int omode, int epi, const GemmParams& p, hipStream_t s);
 
 // ---- attention (attention.hip) -----------------------------------------------------------
 // qkv [B*S][3d] (q | k | v, heads contiguous inside each), ctx [B*S][d]
@@ -49,8 +49,11 @@ hipError_t launch_attention2(const float* qkv, float* ctx, int B, int S, int H, 
 
 // ---- misc (misc.hip) ---------------------------------------------------------------------
 // out = LayerNorm(x + res) (res may be nullptr)
+// compact_S > 0: rows are [B, S] tokens and token 0 of every sample is dropped from the output ([B, S-1, d])
 hipError_t launch_layernorm(const float* x, const float* res, const float* gamma, const float* beta, float* out,
-                            int rows, int d, hipStream_t s);
+                            int rows, int d, int compact_S, hipStream_t s);
+hipError_t launch_transpose_in(const float* x, float* xt, int B, int Bsrc, int J, int T, int ldx, hipStream_t s);
+hipError_t launch_transpose_out(const float* yt, float* y, int B, int J, int T, int ldy, hipStream_t s);
 // out[m][n] = act(sum_k A[m*lda+k] * W[n*ldw+k] + bias[n]);  act: 0 none, 1 SiLU.  K arbitrary.
 hipError_t launch_small_linear(const float* A, int lda, const float* W, int ldw, const float* bias,
                                float* out, int ldo, int M, int N, int K, int act, hipStream_t s);

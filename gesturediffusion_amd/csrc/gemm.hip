@@ -218,6 +218,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
     X(A_ROWS, B_WEIGHT, OUT_ROWS, EPI_GELU)          \
     X(A_ROWS, B_WEIGHT, OUT_ROWS, EPI_RES)           \
     X(A_ROWS, B_WEIGHT, OUT_ROWS, EPI_RES_VEC)       \
+    X(A_ROWS, B_WEIGHT, OUT_TOKROWS, EPI_RES)        \
     X(A_POSE, B_WEIGHT, OUT_ROWS, EPI_BIAS)          \
     X(A_POSE, B_WEIGHT, OUT_TOKROWS, EPI_RES)        \
     X(A_ROWS, B_TOKENS, OUT_POSE, EPI_BIAS)

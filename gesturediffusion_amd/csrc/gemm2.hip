@@ -59,7 +59,7 @@ template <int N>
 __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 template <int MB, int NBW, int BK, int NST>
-__global__ __launch_bounds__(512, 1) void gemm4_kernel(const GemmParams p, const int epi, const int ntn,
+__global__ __launch_bounds__(512, 1) void gemm4_kernel(const GemmParams p, const int epi, const int omode, const int ntn,
                                                        const int ntiles, unsigned long long* dbg) {
 #if defined(__HIP_DEVICE_COMPILE__)   // the host pass only needs the launch stub (the buffer-resource builtins are device-only)
     constexpr int BM = MB * 16, WN = NBW * 16, BN = WN * 4;
@@ -210,20 +210,58 @@ __global__ __launch_bounds__(512, 1) void gemm4_kernel(const GemmParams p, const
             const int tile = lid + tile_i * G;
             ++tile_i;
             const int m0 = (tile / ntn) * BM, n0 = (tile % ntn) * BN;
+            const bool rowmap = omode == OUT_TOKROWS;
+            if (!rowmap && !p.R && !p.V) {
+                // plain epilogue (the four encoder GEMMs): row pointers are base + constant * ldc
 #pragma unroll
-            for (int j = 0; j < NBW; ++j) {
-                const int n = n0 + wave * WN + j * 16 + l15;
-                const float bv = bias_lds[n];
-                float* cp = p.C + (long)(m0 + 4 * lq) * p.ldc + n;
+                for (int j = 0; j < NBW; ++j) {
+                    const int n = n0 + wave * WN + j * 16 + l15;
+                    const float bv = bias_lds[n];
+                    float* cp = p.C + (long)(m0 + 4 * lq) * p.ldc + n;
+#pragma unroll
+                    for (int i = 0; i < MB; ++i) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            float v = acc[i][j][e] + bv;
+                            if (epi == EPI_GELU) v = gelu_fast(v);
+                            cp[(long)(i * 16 + e) * p.ldc] = v;
+                        }
+                        acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    }
+                }
+            } else {
+                // general epilogue (boundary linears): token-row map, hoisted per-token term R, per-sample vector V
+                const bool need_b = rowmap || p.V != nullptr;
 #pragma unroll
                 for (int i = 0; i < MB; ++i) {
+                    // sample index of this lane's 4 rows: one division per 16-row block, then at most one sample
+                    // boundary inside it when T >= 16
+                    int bs[4] = {0, 0, 0, 0};
+                    if (need_b) {
+                        const int mb0 = m0 + i * 16;
+                        const int bb0 = mb0 / p.T, tt0 = mb0 - bb0 * p.T;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        float v = acc[i][j][e] + bv;
-                        if (epi == EPI_GELU) v = gelu_fast(v);
-                        cp[(long)(i * 16 + e) * p.ldc] = v;
+                        for (int e = 0; e < 4; ++e) {
+                            const int r = tt0 + 4 * lq + e;
+                            bs[e] = p.T >= 16 ? bb0 + (r >= p.T ? 1 : 0) : bb0 + r / p.T;
+                        }
                     }
-                    acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int j = 0; j < NBW; ++j) {
+                        const int n = n0 + wave * WN + j * 16 + l15;
+                        const float bv = bias_lds[n];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const int m = m0 + i * 16 + 4 * lq + e;
+                            const long row_out = rowmap ? (long)m + bs[e] + 1 : (long)m;
+                            float v = acc[i][j][e] + bv;
+                            if (p.R) v += p.R[row_out * p.ldr + n];
+                            if (p.V) v += p.V[(long)bs[e] * p.ldv + n];
+                            if (epi == EPI_GELU) v = gelu_fast(v);
+                            p.C[row_out * p.ldc + n] = v;
+                        }
+                        acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    }
                 }
             }
         }
@@ -249,7 +287,7 @@ constexpr size_t g4_lds_bytes(int N) {
 }
 
 template <int MB, int NBW, int BK, int NST>
-static hipError_t launch_cfg(const GemmParams& p, int epi, int num_cus, hipStream_t s) {
+static hipError_t launch_cfg(const GemmParams& p, int epi, int omode, int num_cus, hipStream_t s) {
     constexpr int BM = MB * 16, BN = NBW * 64;
     static_assert(g4_lds_bytes<MB, NBW, BK, NST>(2048) <= 160 * 1024, "tile does not fit the 160 KiB LDS");
     const size_t lds = g4_lds_bytes<MB, NBW, BK, NST>(p.N);
@@ -263,7 +301,7 @@ static hipError_t launch_cfg(const GemmParams& p, int epi, int num_cus, hipStrea
     const int ntm = (p.M + BM - 1) / BM, ntn = p.N / BN;
     const int ntiles = ntm * ntn;
     const int grid = ntiles < num_cus ? ntiles : num_cus;
-    hipLaunchKernelGGL((gemm4_kernel<MB, NBW, BK, NST>), dim3(grid), dim3(512), lds, s, p, epi, ntn, ntiles,
+    hipLaunchKernelGGL((gemm4_kernel<MB, NBW, BK, NST>), dim3(grid), dim3(512), lds, s, p, epi, omode, ntn, ntiles,
                        g2_dbg_buf);
     return hipGetLastError();
 }
@@ -300,12 +338,12 @@ int gemm2_num_cus() {
     return n;
 }
 
-bool gemm2_supported(int epi, const GemmParams& p) {
-    return (epi == EPI_BIAS || epi == EPI_GELU) && p.K % 32 == 0 && p.N % 64 == 0 && p.N <= 2048 && p.lda % 4 == 0 &&
+bool gemm2_supported(int omode, int epi, const GemmParams& p) {
+    return (omode == OUT_ROWS || omode == OUT_TOKROWS) && (epi == EPI_BIAS || epi == EPI_GELU) && p.K % 32 == 0 && p.N % 64 == 0 && p.N <= 2048 && p.lda % 4 == 0 &&
            p.ldw % 4 == 0 && (long)(p.M + 128) * p.lda * 4 < (1L << 31) && (long)(p.N + 128) * p.ldw * 4 < (1L << 31);
 }
 
-hipError_t launch_gemm2(int epi, const GemmParams& p, hipStream_t s) {
+hipError_t launch_gemm2(int omode, int epi, const GemmParams& p, hipStream_t s) {
     const int num_cus = gemm2_num_cus();
     int best_mb = 0, best_nbw = 0, best_bk = 0;
     static int force_mb = -1, force_nbw = -1, force_bk = -1;
@@ -327,7 +365,7 @@ hipError_t launch_gemm2(int epi, const GemmParams& p, hipStream_t s) {
         fprintf(stderr, "[gemm2] M=%d N=%d K=%d epi=%d -> tile %dx%d BK=%d\n", p.M, p.N, p.K, epi, best_mb * 16,
                 best_nbw * 64, best_bk);
 #define X(mb, nbw, bk, nst) \
-    if (best_mb == mb && best_nbw == nbw && best_bk == bk) return launch_cfg<mb, nbw, bk, nst>(p, epi, num_cus, s);
+    if (best_mb == mb && best_nbw == nbw && best_bk == bk) return launch_cfg<mb, nbw, bk, nst>(p, epi, omode, num_cus, s);
     G4_CONFIGS(X)
 #undef X
     return hipErrorInvalidValue;

@@ -22,10 +22,16 @@ template <int VPL>   // float4 per lane: d = 256 * VPL
 __global__ __launch_bounds__(256) void layernorm_vec_kernel(const float* __restrict__ x, const float* __restrict__ res,
                                                              const float* __restrict__ g,
                                                              const float* __restrict__ bta, float* __restrict__ out,
-                                                             int rows, int d) {
+                                                             int rows, int d, int compact_S) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (row >= rows) return;
+    long orow = row;
+    if (compact_S > 0) {                 // drop token 0 of every sample: [B, S, d] -> [B, S-1, d]
+        const int b = row / compact_S;
+        if (row - b * compact_S == 0) return;
+        orow = row - b - 1;
+    }
     const f32x4* xp = reinterpret_cast<const f32x4*>(x + (long)row * d);
     const f32x4* rp = reinterpret_cast<const f32x4*>(res + (long)row * d);
     f32x4 v[VPL];
@@ -46,7 +52,7 @@ __global__ __launch_bounds__(256) void layernorm_vec_kernel(const float* __restr
             q += c * c;
         }
     const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)d + 1e-5f);
-    f32x4* op = reinterpret_cast<f32x4*>(out + (long)row * d);
+    f32x4* op = reinterpret_cast<f32x4*>(out + orow * d);
     const f32x4* gp = reinterpret_cast<const f32x4*>(g);
     const f32x4* bp = reinterpret_cast<const f32x4*>(bta);
 #pragma unroll
@@ -63,10 +69,16 @@ __global__ __launch_bounds__(256) void layernorm_vec_kernel(const float* __restr
 __global__ __launch_bounds__(256) void layernorm_gen_kernel(const float* __restrict__ x, const float* __restrict__ res,
                                                              const float* __restrict__ g,
                                                              const float* __restrict__ bta, float* __restrict__ out,
-                                                             int rows, int d) {
+                                                             int rows, int d, int compact_S) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (row >= rows) return;
+    long orow = row;
+    if (compact_S > 0) {
+        const int b = row / compact_S;
+        if (row - b * compact_S == 0) return;
+        orow = row - b - 1;
+    }
     const float* xp = x + (long)row * d;
     const float* rp = res + (long)row * d;
     float s = 0.0f;
@@ -79,20 +91,75 @@ __global__ __launch_bounds__(256) void layernorm_gen_kernel(const float* __restr
     }
     const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)d + 1e-5f);
     for (int e = lane; e < d; e += 64)
-        out[(long)row * d + e] = ((res ? xp[e] + rp[e] : xp[e]) - mean) * rstd * g[e] + bta[e];
+        out[orow * d + e] = ((res ? xp[e] + rp[e] : xp[e]) - mean) * rstd * g[e] + bta[e];
 }
 
 hipError_t launch_layernorm(const float* x, const float* res, const float* gamma, const float* beta, float* out,
-                            int rows, int d, hipStream_t s) {
+                            int rows, int d, int compact_S, hipStream_t s) {
     const dim3 grid((rows + 3) / 4), block(256);
     if (d == 512)
-        hipLaunchKernelGGL(layernorm_vec_kernel<2>, grid, block, 0, s, x, res, gamma, beta, out, rows, d);
+        hipLaunchKernelGGL(layernorm_vec_kernel<2>, grid, block, 0, s, x, res, gamma, beta, out, rows, d, compact_S);
     else if (d == 1024)
-        hipLaunchKernelGGL(layernorm_vec_kernel<4>, grid, block, 0, s, x, res, gamma, beta, out, rows, d);
+        hipLaunchKernelGGL(layernorm_vec_kernel<4>, grid, block, 0, s, x, res, gamma, beta, out, rows, d, compact_S);
     else if (d == 256)
-        hipLaunchKernelGGL(layernorm_vec_kernel<1>, grid, block, 0, s, x, res, gamma, beta, out, rows, d);
+        hipLaunchKernelGGL(layernorm_vec_kernel<1>, grid, block, 0, s, x, res, gamma, beta, out, rows, d, compact_S);
     else
-        hipLaunchKernelGGL(layernorm_gen_kernel, grid, block, 0, s, x, res, gamma, beta, out, rows, d);
+        hipLaunchKernelGGL(layernorm_gen_kernel, grid, block, 0, s, x, res, gamma, beta, out, rows, d, compact_S);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// Pose-tensor <-> token-major transposes around the boundary GEMMs (model/mdm.py:350-356 InputProcess permute,
+// :372-380 OutputProcess permute).  32x32 tiles through LDS, coalesced on both sides.  ~26 MB each way at
+// config 2: a few microseconds, and they let both boundary linears run on the persistent GEMM.
+//   in : x [Bsrc, J, T]  -> xt [(b*T + t)*ldx + j], b < B (source sample b % Bsrc), columns j >= J zeroed
+//   out: yt [(b*T + t)*ldy + j] -> y [(b*J + j)*T + t]
+__global__ __launch_bounds__(256) void transpose_in_kernel(const float* __restrict__ x, float* __restrict__ xt, int Bsrc,
+                                                           int J, int T, int ldx) {
+    __shared__ float tile[32][33];
+    const int b = blockIdx.z, t0 = blockIdx.x * 32, j0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;           // 32 x 8
+    const float* xb = x + (long)(b % Bsrc) * J * T;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int j = j0 + ty + 8 * r, t = t0 + tx;
+        tile[ty + 8 * r][tx] = (j < J && t < T) ? xb[(long)j * T + t] : 0.0f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int t = t0 + ty + 8 * r, j = j0 + tx;
+        if (t < T && j < ldx) xt[((long)b * T + t) * ldx + j] = tile[tx][ty + 8 * r];
+    }
+}
+
+__global__ __launch_bounds__(256) void transpose_out_kernel(const float* __restrict__ yt, float* __restrict__ y, int J,
+                                                            int T, int ldy) {
+    __shared__ float tile[32][33];
+    const int b = blockIdx.z, t0 = blockIdx.x * 32, j0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int t = t0 + ty + 8 * r, j = j0 + tx;
+        tile[ty + 8 * r][tx] = (t < T && j < J) ? yt[((long)b * T + t) * ldy + j] : 0.0f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int j = j0 + ty + 8 * r, t = t0 + tx;
+        if (j < J && t < T) y[((long)b * J + j) * T + t] = tile[tx][ty + 8 * r];
+    }
+}
+
+hipError_t launch_transpose_in(const float* x, float* xt, int B, int Bsrc, int J, int T, int ldx, hipStream_t s) {
+    const dim3 grid((T + 31) / 32, (ldx + 31) / 32, B);
+    hipLaunchKernelGGL(transpose_in_kernel, grid, dim3(256), 0, s, x, xt, Bsrc, J, T, ldx);
+    return hipGetLastError();
+}
+
+hipError_t launch_transpose_out(const float* yt, float* y, int B, int J, int T, int ldy, hipStream_t s) {
+    const dim3 grid((T + 31) / 32, (J + 31) / 32, B);
+    hipLaunchKernelGGL(transpose_out_kernel, grid, dim3(256), 0, s, yt, y, J, T, ldy);
     return hipGetLastError();
 }
 
