@@ -392,8 +392,8 @@ static int gemm(int am, int bm, int om, int ep, const GemmParams& p, hipStream_t
         if (ep == EPI_RES_VEC) { q.bias = nullptr; ep2 = EPI_BIAS; }
         if (gemm2_supported(om, ep2, q)) {
             e = launch_gemm2(om, ep2, q, s);
-            if (e != hipSuccess) return fail(std::string("launch_gemm2: ") + hipGetErrorString(e));
-            return 0;
+            if (e == hipSuccess) return 0;
+            if (e != hipErrorNotSupported) return fail(std::string("launch_gemm2: ") + hipGetErrorString(e));
         }
     }
     e = launch_gemm(am, bm, om, ep, p, s);

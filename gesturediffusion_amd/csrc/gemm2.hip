@@ -289,7 +289,7 @@ constexpr size_t g4_lds_bytes(int N) {
 template <int MB, int NBW, int BK, int NST>
 static hipError_t launch_cfg(const GemmParams& p, int epi, int omode, int num_cus, hipStream_t s) {
     constexpr int BM = MB * 16, BN = NBW * 64;
-    static_assert(g4_lds_bytes<MB, NBW, BK, NST>(2048) <= 160 * 1024, "tile does not fit the 160 KiB LDS");
+    static_assert(g4_lds_bytes<MB, NBW, BK, NST>(1024) <= 160 * 1024, "tile does not fit the 160 KiB LDS");
     const size_t lds = g4_lds_bytes<MB, NBW, BK, NST>(p.N);
     static size_t attr_lds = 0;
     if (lds > attr_lds) {
@@ -306,12 +306,14 @@ static hipError_t launch_cfg(const GemmParams& p, int epi, int omode, int num_cu
     return hipGetLastError();
 }
 
-// (MB, NBW, BK, NST): tile = 16*MB x 64*NBW, K slab BK, NST LDS stages (all fit 160 KiB with N <= 2048).
+// (MB, NBW, BK, NST): tile = 16*MB x 64*NBW, K slab BK, NST LDS stages (validity incl. the N-float bias copy is checked per problem).
 #define G4_CONFIGS(X) \
     X(4, 2, 32, 4) X(5, 2, 32, 4) X(6, 2, 32, 4) X(8, 2, 32, 3) X(5, 3, 32, 3) X(4, 3, 32, 3) X(4, 1, 64, 3) X(5, 1, 64, 3) X(4, 1, 32, 4) X(5, 1, 32, 4) X(8, 1, 32, 4)
 
-static bool g4_valid(int mb, int nbw, int bk, const GemmParams& p) {
-    return p.N % (nbw * 64) == 0 && p.K % bk == 0 && p.N <= 2048;
+static bool g4_valid(int mb, int nbw, int bk, int nst, const GemmParams& p) {
+    const size_t rowb = (size_t)(bk + 8) * 4;
+    const size_t stage = (mb * 16 * rowb + 1023) / 1024 * 1024 + (nbw * 64 * rowb + 1023) / 1024 * 1024;
+    return p.N % (nbw * 64) == 0 && p.K % bk == 0 && nst * stage + (size_t)p.N * 4 <= 160 * 1024;   // + bias copy
 }
 
 // Estimated cycles of a tile shape: rounds * (K steps * (MFMA cycles per step + per-step overhead) + per-tile cost).
@@ -339,7 +341,7 @@ int gemm2_num_cus() {
 }
 
 bool gemm2_supported(int omode, int epi, const GemmParams& p) {
-    return (omode == OUT_ROWS || omode == OUT_TOKROWS) && (epi == EPI_BIAS || epi == EPI_GELU) && p.K % 32 == 0 && p.N % 64 == 0 && p.N <= 2048 && p.lda % 4 == 0 &&
+    return (omode == OUT_ROWS || omode == OUT_TOKROWS) && (epi == EPI_BIAS || epi == EPI_GELU) && p.K % 32 == 0 && p.N % 64 == 0 && p.N <= 8192 && p.lda % 4 == 0 &&
            p.ldw % 4 == 0 && (long)(p.M + 128) * p.lda * 4 < (1L << 31) && (long)(p.N + 128) * p.ldw * 4 < (1L << 31);
 }
 
@@ -354,13 +356,14 @@ hipError_t launch_gemm2(int omode, int epi, const GemmParams& p, hipStream_t s) 
     static const bool debug = getenv("GDX_GEMM_DEBUG") != nullptr;
     double best = 1e30;
 #define X(mb, nbw, bk, nst)                                                                       \
-    if (g4_valid(mb, nbw, bk, p)) {                                                               \
+    if (g4_valid(mb, nbw, bk, nst, p)) {                                                               \
         double c = g4_cost(mb, nbw, bk, p.M, p.N, p.K, num_cus);                                  \
         if (force_mb == mb && force_nbw == nbw && force_bk == bk) c = 0.0;                        \
         if (c < best) { best = c; best_mb = mb; best_nbw = nbw; best_bk = bk; }                   \
     }
     G4_CONFIGS(X)
 #undef X
+    if (!best_mb) return hipErrorNotSupported;      // no tile shape fits: the caller falls back to gemm.hip
     if (debug)
         fprintf(stderr, "[gemm2] M=%d N=%d K=%d epi=%d -> tile %dx%d BK=%d\n", p.M, p.N, p.K, epi, best_mb * 16,
                 best_nbw * 64, best_bk);
