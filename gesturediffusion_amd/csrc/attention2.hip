@@ -33,7 +33,7 @@ __device__ __forceinline__ void a2_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)
 
 template <int HD, int QB>   // QB must be 2 (the dispatch below instantiates 0 / 1 / 2 active blocks)
 __global__ __launch_bounds__(512, 1) void attention2_kernel(const float* __restrict__ qkv, float* __restrict__ ctx,
-                                                            int S, int H, int d, float scale, int dbgf) {
+                                                            int S, int H, int d, float scale) {
 #if defined(__HIP_DEVICE_COMPILE__)   // buffer-resource builtins are device-only (the host pass needs just the stub)
     constexpr int KS = HD + 8;            // K row stride (floats)
     constexpr int NKK = HD / 16;          // b128 fragment groups along head_dim (QK^T)
@@ -156,7 +156,6 @@ __global__ __launch_bounds__(512, 1) void attention2_kernel(const float* __restr
             for (int qi = 0; qi < QB; ++qi) s[qi] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int kk = 0; kk < NKK; ++kk) {
-                if (dbgf & 8) break;
                 const f32x4 kf = *reinterpret_cast<const f32x4*>(&Ks[(kb * 16 + l15) * KS + 16 * kk + 4 * lq]);
 #pragma unroll
                 for (int c = 0; c < 4; ++c)
@@ -170,7 +169,6 @@ __global__ __launch_bounds__(512, 1) void attention2_kernel(const float* __restr
             //      than RESCALE_THR, so after the first key block the common path is mask + exp + add.
 #pragma unroll
             for (int qi = 0; qi < NQ; ++qi) {
-                if (dbgf & 2) break;
                 float mx = -INFINITY;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
@@ -202,7 +200,6 @@ __global__ __launch_bounds__(512, 1) void attention2_kernel(const float* __restr
             for (int e = 0; e < 4; ++e)
 #pragma unroll
                 for (int g = 0; g < NG; ++g) {
-                    if (dbgf & 4) break;
                     const f32x4 vf = *reinterpret_cast<const f32x4*>(&Vs[(kb * 16 + 4 * lq + e) * HD + 64 * g + 4 * l15]);
 #pragma unroll
                     for (int c = 0; c < 4; ++c)
@@ -256,8 +253,7 @@ static hipError_t launch_a2(const float* qkv, float* ctx, int B, int S, int H, i
         attr_done = true;
     }
     const float scale = 1.0f / sqrtf((float)HD);
-    static const int dbgf = getenv("GDX_ATTN_DBG") ? atoi(getenv("GDX_ATTN_DBG")) : 0;   // measurement only
-    hipLaunchKernelGGL((attention2_kernel<HD, QB>), dim3(B * H), dim3(512), lds, s, qkv, ctx, S, H, d, scale, dbgf);
+    hipLaunchKernelGGL((attention2_kernel<HD, QB>), dim3(B * H), dim3(512), lds, s, qkv, ctx, S, H, d, scale);
     return hipGetLastError();
 }
 

@@ -1,8 +1,9 @@
-// fp32 GEMM on the gfx950 matrix cores: C = A * W^T with fused epilogues.
-//
-// This is the kernel behind every dense projection of the denoiser step
+// fp32 GEMM on the gfx950 matrix cores: C = A * W^T with fused epilogues -- the FIRST GEMM of this build and now
+// the fallback for shapes gemm2.hip does not take (N not a multiple of 64, K not a multiple of 32, no tile that fits
+// the LDS).  It covers every dense projection of the denoiser step
 // (reference model/mdm.py:90-96 -> nn.TransformerEncoderLayer QKV / out-proj / linear1 / linear2,
-//  model/mdm.py:350-356 InputProcess, :169 project_to_lat, :372-380 OutputProcess).
+//  model/mdm.py:350-356 InputProcess, :169 project_to_lat, :372-380 OutputProcess); round-1a numbers
+// (profiles/r01a_*) were measured with it.
 //
 // Design (MI355X_MICROARCH.md, cdna_hip_programming.md section 3 "FP32-input MFMA"):
 //   * v_mfma_f32_32x32x2_f32: exact fp32 (bitwise an fmaf chain), 64 FLOP/clk/SIMD -> 157 TF peak.
