@@ -358,3 +358,22 @@ def test_error_behaviour_matches_reference(golden_dir):
     with pytest.raises(Exception):            # CPU tensors never fall back to a CPU path
         m(x, t.cpu(), {"seed": seedp, "mfcc": mfcc})
     assert m.eval() is m                      # superset of the reference (which returns None)
+
+
+@pytest.mark.parametrize("extra", [["--arch_version", "mdm_old", "--num_frames", "23", "--guidance_param", "1"],
+                                   ["--arch_version", "mdm", "--num_frames", "20", "--rng", "philox"],
+                                   ["--arch_version", "mdm", "--num_frames", "20", "--sampler", "ddim", "--timestep_respacing", "ddim10"]])
+def test_generate_cli_synthetic(tmp_path, extra):
+    """The sample.generate CLI end to end (args -> factory -> CFG wrapper -> chunked autoregressive sampling with
+    seed chaining -> results.npy) on synthetic conditioning."""
+    from gesturediffusion_amd.sample import generate
+    out = tmp_path / "out"
+    base = ["--synthetic", "--latent_dim", "128", "--layers", "2", "--num_samples", "3", "--chunks", "2",
+            "--synthetic_njoints", "37", "--output_dir", str(out), "--seed", "7"]
+    if "--timestep_respacing" not in extra:
+        base += ["--timestep_respacing", "25"]
+    assert generate.main(base + extra) == 0
+    res = np.load(out / "results.npy", allow_pickle=True).item()      # written by this test a moment ago
+    frames = int(extra[extra.index("--num_frames") + 1])
+    assert res["motion"].shape == (3, 37, 1, 2 * frames) and np.isfinite(res["motion"]).all()
+    assert np.abs(res["motion"]).max() > 0
