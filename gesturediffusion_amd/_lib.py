@@ -18,6 +18,7 @@ EXPORTS = [
     "gdx_create", "gdx_destroy", "gdx_last_error", "gdx_set_weight", "gdx_weights_ready", "gdx_prepare",
     "gdx_set_condition", "gdx_forward", "gdx_set_keep_taps", "gdx_get_tap", "gdx_sampler_update", "gdx_q_sample",
     "gdx_randn", "gdx_sample_loop", "gdx_bench_ffn_gemm", "gdx_bench_gemm", "gdx_forward_flops", "gdx_profile_begin", "gdx_profile_end", "gdx_bench_attention",
+    "gdx_linear_f16", "gdx_bench_gemm_f16",
 ]
 
 
@@ -27,7 +28,7 @@ class GdxError(RuntimeError):
 
 class Config(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("arch", "njoints", "latent_dim", "ff_size", "num_layers", "num_heads",
-                                         "seed_poses", "mfcc_dim", "cl_head", "window")]
+                                         "seed_poses", "mfcc_dim", "cl_head", "window", "compute_dtype")]
 
 
 class UpdateArgs(C.Structure):
@@ -89,6 +90,8 @@ def load():
         "gdx_forward_flops": [vp, i32, C.POINTER(C.c_double)],
         "gdx_bench_gemm": [i32, i32, i32, i32, i32, C.POINTER(C.c_float), vp],
         "gdx_bench_attention": [i32, i32, i32, i32, i32, i32, C.POINTER(C.c_float), vp],
+        "gdx_linear_f16": [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp],
+        "gdx_bench_gemm_f16": [i32, i32, i32, i32, i32, C.POINTER(C.c_float), vp],
         "gdx_profile_begin": [vp, i32],
         "gdx_profile_end": [vp, C.POINTER(C.c_float), C.POINTER(i32)],
     }

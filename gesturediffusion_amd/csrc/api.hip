@@ -37,10 +37,21 @@ __global__ void pack_weight_kernel(const float* __restrict__ src, int src_ld, in
     dst[i] = (r < n && c < k) ? src[(long)r * src_ld + col0 + c] : 0.0f;
 }
 
+// dst[r][c] = (r < n && c < k) ? (fp16) src[r*src_ld + col0 + c] : 0      (dst is [npad][kpad] halves)
+__global__ void pack_weight_f16_kernel(const float* __restrict__ src, int src_ld, int col0, int n, int k,
+                                       _Float16* __restrict__ dst, int npad, int kpad) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)npad * kpad) return;
+    const int r = i / kpad, c = i % kpad;
+    dst[i] = (r < n && c < k) ? (_Float16)src[(long)r * src_ld + col0 + c] : (_Float16)0.0f;
+}
+
 struct Packed {          // a Linear weight [n][k] packed to [npad][kpad] (+ bias [npad])
     float* w = nullptr;
     float* bias = nullptr;
     int n = 0, k = 0, npad = 0, kpad = 0;
+    _Float16* w16 = nullptr;             // fp16 mode: [npad16][kpad16], rows padded to 256, K to 64 (gemmh.hip)
+    int npad16 = 0, kpad16 = 0;
 };
 
 struct Layer {
@@ -56,6 +67,9 @@ namespace gdx { extern unsigned long long* g2_dbg_buf; }
 struct gdx_model {
     gdx_config_t cfg;
     int d, J, ff, L, H;
+    bool f16 = false;                 // cfg.compute_dtype == GDX_DTYPE_F16: fp16 MFMA operands, fp32 accumulate
+    _Float16 *xt16 = nullptr, *xa16 = nullptr, *xb16 = nullptr, *qkv16 = nullptr, *ctx16 = nullptr, *ffb16 = nullptr,
+             *emb16 = nullptr, *xc16 = nullptr;
     std::set<std::string> have;
     std::vector<std::string> required;
     std::vector<void*> allocs;        // weight allocations
@@ -89,6 +103,15 @@ static int dev_alloc(std::vector<void*>& pool, void** p, size_t bytes) {
     return 0;
 }
 
+static int pack_f16_into(_Float16* dst, const float* src, int n, int src_ld, int col0, int k, int npad, int kpad,
+                         hipStream_t s) {
+    const long total = (long)npad * kpad;
+    hipLaunchKernelGGL(pack_weight_f16_kernel, dim3((total + 255) / 256), dim3(256), 0, s, src, src_ld, col0, n, k, dst,
+                       npad, kpad);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
 static int pack(gdx_model* h, Packed& P, const float* src, int n, int src_ld, int col0, int k, hipStream_t s) {
     P.n = n; P.k = k; P.npad = round_up(n, 128); P.kpad = round_up(k, 32);
     if (!P.w && dev_alloc(h->allocs, (void**)&P.w, sizeof(float) * P.npad * (size_t)P.kpad)) return -1;
@@ -96,6 +119,11 @@ static int pack(gdx_model* h, Packed& P, const float* src, int n, int src_ld, in
     hipLaunchKernelGGL(pack_weight_kernel, dim3((total + 255) / 256), dim3(256), 0, s, src, src_ld, col0, n, k, P.w,
                        P.npad, P.kpad);
     HIPCHK(hipGetLastError());
+    if (h->f16) {
+        P.npad16 = round_up(n, 256); P.kpad16 = round_up(k, 64);
+        if (!P.w16 && dev_alloc(h->allocs, (void**)&P.w16, 2 * (size_t)P.npad16 * P.kpad16)) return -1;
+        if (pack_f16_into(P.w16, src, n, src_ld, col0, k, P.npad16, P.kpad16, s)) return -1;
+    }
     return 0;
 }
 
@@ -113,6 +141,9 @@ extern "C" const char* gdx_last_error(void) { return g_err.c_str(); }
 extern "C" int gdx_create(const gdx_config_t* cfg, gdx_handle_t* out) {
     if (!cfg || !out) return fail("gdx_create: null argument");
     if (cfg->arch != GDX_ARCH_MDM && cfg->arch != GDX_ARCH_MDM_OLD) return fail("gdx_create: unknown arch");
+    if (cfg->compute_dtype != GDX_DTYPE_F32 && cfg->compute_dtype != GDX_DTYPE_F16) return fail("gdx_create: unknown compute_dtype");
+    if (cfg->compute_dtype == GDX_DTYPE_F16 && (cfg->latent_dim % 64 || cfg->ff_size % 64))
+        return fail("gdx_create: fp16 mode needs latent_dim and ff_size to be multiples of 64");
     if (cfg->latent_dim <= 0 || cfg->latent_dim % 32) return fail("gdx_create: latent_dim must be a multiple of 32");
     if (cfg->ff_size <= 0 || cfg->ff_size % 32) return fail("gdx_create: ff_size must be a multiple of 32");
     if (cfg->num_heads <= 0 || cfg->latent_dim % cfg->num_heads) return fail("gdx_create: latent_dim % num_heads != 0");
@@ -129,6 +160,7 @@ extern "C" int gdx_create(const gdx_config_t* cfg, gdx_handle_t* out) {
     if (e != hipSuccess) return fail(std::string("gemm_init: ") + hipGetErrorString(e));
     gdx_model* h = new gdx_model();
     h->cfg = *cfg;
+    h->f16 = cfg->compute_dtype == GDX_DTYPE_F16;
     h->d = cfg->latent_dim; h->J = cfg->njoints; h->ff = cfg->ff_size; h->L = cfg->num_layers; h->H = cfg->num_heads;
     h->layers.resize(h->L);
     auto& r = h->required;
@@ -325,6 +357,17 @@ extern "C" int gdx_prepare(gdx_handle_t h, int32_t batch, int32_t frames) {
     const size_t NT = B2 * frames + 128;
     if (A(&h->xt, NT * round_up(h->J, 32)) || A(&h->xc, NT * d) || A(&h->x0t, NT * h->ldo)) return -1;
     if (h->cfg.arch == GDX_ARCH_MDM && (A(&h->emb_pose, (B2 * frames + 128) * d) || A(&h->xseq, (B2 * frames + 128) * d))) return -1;
+    if (h->f16) {
+        auto H16 = [&](_Float16** p, size_t n) {
+            if (dev_alloc(h->ws_allocs, (void**)p, n * 2)) return -1;
+            if (hipMemset(*p, 0, n * 2) != hipSuccess) return fail("gdx_prepare: hipMemset failed");
+            return 0;
+        };
+        if (H16(&h->xt16, NT * round_up(h->J, 64)) || H16(&h->xa16, N * d) || H16(&h->xb16, N * d) ||
+            H16(&h->qkv16, N * 3 * d) || H16(&h->ctx16, N * d) || H16(&h->ffb16, N * h->ff) || H16(&h->xc16, NT * d))
+            return -1;
+        if (h->cfg.arch == GDX_ARCH_MDM && H16(&h->emb16, NT * d)) return -1;
+    }
     if (h->keep_taps) {
         h->taps.resize(h->L + 1);
         for (auto& t : h->taps)
@@ -403,8 +446,12 @@ static int gemm(int am, int bm, int om, int ep, const GemmParams& p, hipStream_t
 
 // The per-step kernel sequence.  temb: [*, d] rows (row stride tstride, 0 = shared by the batch).
 // Writes x0 for Beff samples into x0_out ([Beff, J, T]).
+static int forward_core_f16(gdx_model* h, const float* x, const float* temb, int tstride, int mode, float* x0_out,
+                            hipStream_t s);
+
 static int forward_core(gdx_model* h, const float* x, const float* temb, int tstride, int mode, float* x0_out,
                         hipStream_t s) {
+    if (h->f16) return forward_core_f16(h, x, temb, tstride, mode, x0_out, s);
     const int B = h->B, T = h->T, S = h->S, d = h->d, J = h->J;
     const int Beff = mode == GDX_CFG ? 2 * B : B;
     const float* seed_emb = mode == GDX_UNCOND ? h->seed_cat + (size_t)B * d : h->seed_cat;
@@ -414,18 +461,18 @@ static int forward_core(gdx_model* h, const float* x, const float* temb, int tst
     const int Jp = h->in_x.kpad;
     HIPCHK(launch_transpose_in(x, h->xt, Beff, B, J, T, Jp, s));
     if (h->cfg.arch == GDX_ARCH_MDM_OLD) {
-        HIPCHK(launch_token0(temb, tstride, seed_emb, h->pe, h->xa, nullptr, Beff, B, S, d, s));
+        HIPCHK(launch_token0(temb, tstride, seed_emb, h->pe, h->xa, nullptr, nullptr, Beff, B, S, d, s));
         // frames -> rows (b, t+1) of the encoder input, + hoisted MFCC/bias/PE term      (model/mdm_old.py:104-112)
         p = GemmParams{h->xt, Jp, h->in_x.w, h->in_x.kpad, nullptr, h->addend, d, nullptr, 0, h->xa, d, Beff * T, d, Jp, T, B};
         if (gemm(A_ROWS, B_WEIGHT, OUT_TOKROWS, EPI_RES, p, s)) return -1;
     } else {
-        HIPCHK(launch_token0(temb, tstride, seed_emb, nullptr, h->xa, h->coa, Beff, B, S, d, s));
+        HIPCHK(launch_token0(temb, tstride, seed_emb, nullptr, h->xa, nullptr, h->coa, Beff, B, S, d, s));
         p = GemmParams{h->xt, Jp, h->in_x.w, h->in_x.kpad, h->in_x.bias, nullptr, 0, nullptr, 0, h->emb_pose, d, Beff * T, d, Jp, T, B};
         if (gemm(A_ROWS, B_WEIGHT, OUT_ROWS, EPI_BIAS, p, s)) return -1;
         HIPCHK(launch_small_linear(h->coa, d, h->proj_coa.w, h->proj_coa.kpad, nullptr, h->c2, d, Beff, d, d, 0, s));
         p = GemmParams{h->emb_pose, d, h->proj_pose.w, h->proj_pose.kpad, nullptr, h->addend, d, h->c2, d, h->xseq, d, Beff * T, d, d, T, B};
         if (gemm(A_ROWS, B_WEIGHT, OUT_ROWS, EPI_RES_VEC, p, s)) return -1;
-        HIPCHK(launch_local_attention(h->xseq, h->rope_cos, h->rope_sin, h->xa, Beff, T, d, h->cfg.cl_head,
+        HIPCHK(launch_local_attention(h->xseq, h->rope_cos, h->rope_sin, h->xa, nullptr, Beff, T, d, h->cfg.cl_head,
                                       h->cfg.window, s));
     }
     if (h->keep_taps)
@@ -442,7 +489,7 @@ static int forward_core(gdx_model* h, const float* x, const float* temb, int tst
         // x = LN1(x + out_proj(ctx)): the residual add rides in the LayerNorm kernel (see gemm2.hip)
         p = GemmParams{h->ctx, d, ly.out.w, ly.out.kpad, ly.out.bias, nullptr, 0, nullptr, 0, h->tmp, d, N, d, d, T, B};
         if (gemm(A_ROWS, B_WEIGHT, OUT_ROWS, EPI_BIAS, p, s)) return -1;
-        HIPCHK(launch_layernorm(h->tmp, h->xa, ly.g1, ly.b1, h->xb, N, d, 0, s));
+        HIPCHK(launch_layernorm(h->tmp, h->xa, ly.g1, ly.b1, h->xb, nullptr, N, d, 0, s));
         p = GemmParams{h->xb, d, ly.ff1.w, ly.ff1.kpad, ly.ff1.bias, nullptr, 0, nullptr, 0, h->ffb, h->ff, N, h->ff, d, T, B};
         const bool stamp = h->prof && h->prof_used + 2 <= h->prof_ev.size();
         if (stamp) HIPCHK(hipEventRecord(h->prof_ev[h->prof_used], s));
@@ -455,14 +502,88 @@ static int forward_core(gdx_model* h, const float* x, const float* temb, int tst
         if (gemm(A_ROWS, B_WEIGHT, OUT_ROWS, EPI_BIAS, p, s)) return -1;
         const bool last = l + 1 == h->L;
         // the last layer's output is only needed without token 0 (model/mdm.py:219): write it compacted [Beff*T, d]
-        if (!last || h->keep_taps) HIPCHK(launch_layernorm(h->tmp, h->xb, ly.g2, ly.b2, h->xa, N, d, 0, s));
-        if (last) HIPCHK(launch_layernorm(h->tmp, h->xb, ly.g2, ly.b2, h->xc, N, d, S, s));
+        if (!last || h->keep_taps) HIPCHK(launch_layernorm(h->tmp, h->xb, ly.g2, ly.b2, h->xa, nullptr, N, d, 0, s));
+        if (last) HIPCHK(launch_layernorm(h->tmp, h->xb, ly.g2, ly.b2, h->xc, nullptr, N, d, S, s));
         if (h->keep_taps)
             HIPCHK(hipMemcpyAsync(h->taps[l + 1], h->xa, sizeof(float) * (size_t)N * d, hipMemcpyDeviceToDevice, s));
     }
     // OutputProcess (model/mdm.py:372-380): token-major GEMM, then the permute back to [B, J, 1, T]
     p = GemmParams{h->xc, d, h->outp.w, h->outp.kpad, h->outp.bias, nullptr, 0, nullptr, 0, h->x0t, h->ldo, Beff * T, h->ldo, d, T, B};
     if (gemm(A_ROWS, B_WEIGHT, OUT_ROWS, EPI_BIAS, p, s)) return -1;
+    HIPCHK(launch_transpose_out(h->x0t, x0_out, Beff, J, T, h->ldo, s));
+    return 0;
+}
+
+// fp16 mode: one GEMM through gemmh.hip.  A [M][K16] halves with exactly M readable rows.
+static int gemm_f16(const _Float16* A, int lda, const Packed& P, const float* bias, const float* R, int ldr,
+                    const float* V, int ldv, float* C32, int ldc32, _Float16* C16, int ldc16, int M, int N, int T,
+                    int rowmap, int gelu, hipStream_t s) {
+    const size_t ab = (size_t)M * lda * 2, wb = (size_t)P.npad16 * P.kpad16 * 2;
+    if (ab >= (1ull << 31) || wb >= (1ull << 31)) return fail("gemm_f16: operand exceeds the 2 GiB buffer-descriptor range");
+    if (N > P.npad16) return fail("gemm_f16: N exceeds the packed weight");
+    GemmHParams p{A, lda, P.w16, P.kpad16, (int)ab, (int)wb, bias, R, ldr, V, ldv, C32, ldc32, C16, ldc16,
+                  M, N, P.kpad16, T, rowmap, gelu};
+    hipError_t e = launch_gemmh(p, s);
+    if (e != hipSuccess) return fail(std::string("launch_gemmh: ") + hipGetErrorString(e));
+    return 0;
+}
+
+// The per-step kernel sequence of the fp16 mode: every GEMM operand (activations and weights) is fp16, every
+// accumulation, bias / residual add, LayerNorm and softmax is fp32, the residual stream is kept in fp32 (xa / xb)
+// next to the fp16 copy the next GEMM reads (xa16 / xb16).
+static int forward_core_f16(gdx_model* h, const float* x, const float* temb, int tstride, int mode, float* x0_out,
+                            hipStream_t s) {
+    const int B = h->B, T = h->T, S = h->S, d = h->d, J = h->J;
+    const int Beff = mode == GDX_CFG ? 2 * B : B;
+    const float* seed_emb = mode == GDX_UNCOND ? h->seed_cat + (size_t)B * d : h->seed_cat;
+    const int N = Beff * S;
+    const int Jp = h->in_x.kpad16;
+    HIPCHK(launch_transpose_in_f16(x, h->xt16, Beff, B, J, T, Jp, s));
+    if (h->cfg.arch == GDX_ARCH_MDM_OLD) {
+        HIPCHK(launch_token0(temb, tstride, seed_emb, h->pe, h->xa, h->xa16, nullptr, Beff, B, S, d, s));
+        if (gemm_f16(h->xt16, Jp, h->in_x, nullptr, h->addend, d, nullptr, 0, h->xa, d, h->xa16, d, Beff * T, d, T, 1, 0, s))
+            return -1;
+    } else {
+        HIPCHK(launch_token0(temb, tstride, seed_emb, nullptr, h->xa, h->xa16, h->coa, Beff, B, S, d, s));
+        if (gemm_f16(h->xt16, Jp, h->in_x, h->in_x.bias, nullptr, 0, nullptr, 0, nullptr, 0, h->emb16, d, Beff * T, d, T, 0, 0, s))
+            return -1;
+        HIPCHK(launch_small_linear(h->coa, d, h->proj_coa.w, h->proj_coa.kpad, nullptr, h->c2, d, Beff, d, d, 0, s));
+        if (gemm_f16(h->emb16, d, h->proj_pose, nullptr, h->addend, d, h->c2, d, h->xseq, d, nullptr, 0, Beff * T, d, T, 0, 0, s))
+            return -1;
+        HIPCHK(launch_local_attention(h->xseq, h->rope_cos, h->rope_sin, h->xa, h->xa16, Beff, T, d, h->cfg.cl_head,
+                                      h->cfg.window, s));
+    }
+    if (h->keep_taps)
+        HIPCHK(hipMemcpyAsync(h->taps[0], h->xa, sizeof(float) * (size_t)N * d, hipMemcpyDeviceToDevice, s));
+    for (int l = 0; l < h->L; ++l) {
+        const Layer& ly = h->layers[l];
+        if (gemm_f16(h->xa16, d, ly.qkv, ly.qkv.bias, nullptr, 0, nullptr, 0, h->qkv, 3 * d, nullptr, 0, N, 3 * d, T, 0, 0, s))
+            return -1;
+        if (attention2_supported(S, h->H, d))
+            HIPCHK(launch_attention2(h->qkv, h->ctx, Beff, S, h->H, d, s));
+        else
+            HIPCHK(launch_attention(h->qkv, h->ctx, Beff, S, h->H, d, s));
+        HIPCHK(launch_convert_f16(h->ctx, h->ctx16, (int64_t)N * d, s));
+        if (gemm_f16(h->ctx16, d, ly.out, ly.out.bias, nullptr, 0, nullptr, 0, h->tmp, d, nullptr, 0, N, d, T, 0, 0, s)) return -1;
+        HIPCHK(launch_layernorm(h->tmp, h->xa, ly.g1, ly.b1, h->xb, h->xb16, N, d, 0, s));
+        const bool stamp = h->prof && h->prof_used + 2 <= h->prof_ev.size();
+        if (stamp) HIPCHK(hipEventRecord(h->prof_ev[h->prof_used], s));
+        if (gemm_f16(h->xb16, d, ly.ff1, ly.ff1.bias, nullptr, 0, nullptr, 0, nullptr, 0, h->ffb16, h->ff, N, h->ff, T, 0, 1, s))
+            return -1;
+        if (stamp) {
+            HIPCHK(hipEventRecord(h->prof_ev[h->prof_used + 1], s));
+            h->prof_used += 2;
+        }
+        if (gemm_f16(h->ffb16, h->ff, ly.ff2, ly.ff2.bias, nullptr, 0, nullptr, 0, h->tmp, d, nullptr, 0, N, d, T, 0, 0, s))
+            return -1;
+        const bool last = l + 1 == h->L;
+        if (!last || h->keep_taps) HIPCHK(launch_layernorm(h->tmp, h->xb, ly.g2, ly.b2, h->xa, h->xa16, N, d, 0, s));
+        if (last) HIPCHK(launch_layernorm(h->tmp, h->xb, ly.g2, ly.b2, nullptr, h->xc16, N, d, S, s));
+        if (h->keep_taps)
+            HIPCHK(hipMemcpyAsync(h->taps[l + 1], h->xa, sizeof(float) * (size_t)N * d, hipMemcpyDeviceToDevice, s));
+    }
+    if (gemm_f16(h->xc16, d, h->outp, h->outp.bias, nullptr, 0, nullptr, 0, h->x0t, h->ldo, nullptr, 0, Beff * T, h->ldo, T, 0, 0, s))
+        return -1;
     HIPCHK(launch_transpose_out(h->x0t, x0_out, Beff, J, T, h->ldo, s));
     return 0;
 }
@@ -678,6 +799,75 @@ extern "C" int gdx_bench_gemm(int32_t M, int32_t N, int32_t K, int32_t epi, int3
     }
     free_pool(pool);
     return 0;
+}
+
+extern "C" int gdx_linear_f16(const float* A, const float* W, const float* bias, float* C32, float* C16, int32_t M,
+                              int32_t N, int32_t K, int32_t gelu, void* stream) {
+    if (!A || !W || (!C32 && !C16) || M <= 0 || N <= 0 || K <= 0 || K % 64 || N % 64)
+        return fail("gdx_linear_f16: bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    const int npad = round_up(N, 256);
+    _Float16 *a16 = nullptr, *w16 = nullptr, *c16 = nullptr;
+    std::vector<void*> pool;
+    int rc = 0;
+    if (dev_alloc(pool, (void**)&a16, 2 * (size_t)M * K) || dev_alloc(pool, (void**)&w16, 2 * (size_t)npad * K) ||
+        dev_alloc(pool, (void**)&c16, 2 * (size_t)M * N))
+        rc = -1;
+    if (!rc && launch_convert_f16(A, a16, (int64_t)M * K, s) != hipSuccess) rc = fail("gdx_linear_f16: convert failed");
+    if (!rc) rc = pack_f16_into(w16, W, N, K, 0, K, npad, K, s);
+    if (!rc) {
+        GemmHParams p{a16, K, w16, K, (int)((size_t)M * K * 2), (int)((size_t)npad * K * 2), bias, nullptr, 0, nullptr, 0,
+                      C32, N, C16 ? c16 : nullptr, N, M, N, K, 1, 0, gelu};
+        hipError_t e = launch_gemmh(p, s);
+        if (e != hipSuccess) rc = fail(std::string("launch_gemmh: ") + hipGetErrorString(e));
+    }
+    if (!rc && C16 && launch_convert_f32(c16, C16, (int64_t)M * N, s) != hipSuccess) rc = fail("gdx_linear_f16: convert failed");
+    (void)hipStreamSynchronize(s);
+    free_pool(pool);
+    return rc;
+}
+
+extern "C" int gdx_bench_gemm_f16(int32_t M, int32_t N, int32_t K, int32_t gelu, int32_t iters, float* avg_us, void* stream) {
+    if (!avg_us || M <= 0 || N <= 0 || K <= 0 || K % 64 || N % 64 || iters <= 0) return fail("gdx_bench_gemm_f16: bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    const int npad = round_up(N, 256);
+    float *Af = nullptr, *bias = nullptr;
+    _Float16 *a16 = nullptr, *w16 = nullptr, *c16 = nullptr;
+    std::vector<void*> pool;
+    const size_t nmax = (size_t)(M > npad ? M : npad) * K;
+    if (dev_alloc(pool, (void**)&Af, 4 * nmax) || dev_alloc(pool, (void**)&bias, 4 * (size_t)npad) ||
+        dev_alloc(pool, (void**)&a16, 2 * (size_t)M * K) || dev_alloc(pool, (void**)&w16, 2 * (size_t)npad * K) ||
+        dev_alloc(pool, (void**)&c16, 2 * (size_t)M * N)) {
+        free_pool(pool);
+        return -1;
+    }
+    int rc = 0;
+    // non-trivial operand values (zero operands raise the clock: cdna_hip_programming.md rule 25)
+    if (gdx_randn(Af, 1, (int64_t)M * K, 1, 0, 0, stream) || launch_convert_f16(Af, a16, (int64_t)M * K, s) != hipSuccess ||
+        gdx_randn(Af, 1, (int64_t)npad * K, 2, 0, 0, stream) || launch_convert_f16(Af, w16, (int64_t)npad * K, s) != hipSuccess ||
+        gdx_randn(bias, 1, npad, 4, 0, 0, stream))
+        rc = fail("gdx_bench_gemm_f16: operand fill failed");
+    GemmHParams p{a16, K, w16, K, (int)((size_t)M * K * 2), (int)((size_t)npad * K * 2), bias, nullptr, 0, nullptr, 0,
+                  nullptr, 0, c16, N, M, N, K, 1, 0, gelu};
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (!rc && (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess)) rc = fail("hipEventCreate failed");
+    for (int i = 0; !rc && i < 3; ++i)
+        if (launch_gemmh(p, s) != hipSuccess) rc = fail("launch_gemmh failed");
+    if (!rc) (void)hipEventRecord(e0, s);
+    for (int i = 0; !rc && i < iters; ++i)
+        if (launch_gemmh(p, s) != hipSuccess) rc = fail("launch_gemmh failed");
+    if (!rc) {
+        (void)hipEventRecord(e1, s);
+        (void)hipEventSynchronize(e1);
+        float ms = 0.f;
+        (void)hipEventElapsedTime(&ms, e0, e1);
+        *avg_us = ms * 1000.0f / (float)iters;
+    }
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    (void)hipStreamSynchronize(s);
+    free_pool(pool);
+    return rc;
 }
 
 // Stand-alone attention timing on scratch buffers (measurement helper for tools/attn_one.py).

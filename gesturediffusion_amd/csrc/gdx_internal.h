@@ -39,6 +39,23 @@ hipError_t launch_gemm(int amode, int bmode, int omode, int epi, const GemmParam
 bool gemm2_supported(int omode, int epi, const GemmParams& p);
 hipError_t launch_gemm2(int omode, int epi, const GemmParams& p, hipStream_t s);
 
+// fp16-input / fp32-accumulate persistent GEMM of the reduced-precision mode (gemmh.hip):
+//   C[row_out][n] = act( sum_k A[m][k] W[n][k] + bias[n] + R[row_out][n] + V[m / T][n] ),  row_out = rowmap ? m + m/T + 1 : m
+struct GemmHParams {
+    const _Float16* A; int lda;      // [M][K] halves, K % 64 == 0
+    const _Float16* W; int ldw;      // packed weight, rows padded to a multiple of 256
+    int a_bytes, w_bytes;            // exact extents for the buffer descriptors (reads past them return 0)
+    const float* bias;               // [N] or nullptr
+    const float* R; int ldr;         // fp32 per-output-row term or nullptr
+    const float* V; int ldv;         // fp32 per-sample vector or nullptr
+    float* C32; int ldc32;           // fp32 output or nullptr
+    _Float16* C16; int ldc16;        // fp16 output or nullptr
+    int M, N, K, T;
+    int rowmap, gelu;
+};
+bool gemmh_supported(const GemmHParams& p);
+hipError_t launch_gemmh(const GemmHParams& p, hipStream_t s);
+
 // ---- attention (attention.hip) -----------------------------------------------------------
 // qkv [B*S][3d] (q | k | v, heads contiguous inside each), ctx [B*S][d]
 hipError_t launch_attention(const float* qkv, float* ctx, int B, int S, int H, int d, hipStream_t s);
@@ -50,9 +67,11 @@ hipError_t launch_attention2(const float* qkv, float* ctx, int B, int S, int H, 
 // ---- misc (misc.hip) ---------------------------------------------------------------------
 // out = LayerNorm(x + res) (res may be nullptr)
 // compact_S > 0: rows are [B, S] tokens and token 0 of every sample is dropped from the output ([B, S-1, d])
+// out (fp32) and out16 (fp16 copy for the reduced-precision GEMMs) are each optional
 hipError_t launch_layernorm(const float* x, const float* res, const float* gamma, const float* beta, float* out,
-                            int rows, int d, int compact_S, hipStream_t s);
+                            _Float16* out16, int rows, int d, int compact_S, hipStream_t s);
 hipError_t launch_transpose_in(const float* x, float* xt, int B, int Bsrc, int J, int T, int ldx, hipStream_t s);
+hipError_t launch_transpose_in_f16(const float* x, _Float16* xt, int B, int Bsrc, int J, int T, int ldx, hipStream_t s);
 hipError_t launch_transpose_out(const float* yt, float* y, int B, int J, int T, int ldy, hipStream_t s);
 // out[m][n] = act(sum_k A[m*lda+k] * W[n*ldw+k] + bias[n]);  act: 0 none, 1 SiLU.  K arbitrary.
 hipError_t launch_small_linear(const float* A, int lda, const float* W, int ldw, const float* bias,
@@ -66,11 +85,14 @@ hipError_t launch_mfcc_project(const float* mfcc, const float* W, int ldw, const
 // token 0 of the encoder input: enc[b*S*d + n] = temb[(b%Bmod)*tstride + n] + seed[b*d + n] (+ pe0[n]);
 // also writes coa[b*d+n] (same value without pe0) when coa != nullptr.
 hipError_t launch_token0(const float* temb, int tstride, const float* seed_emb, const float* pe0,
-                         float* enc, float* coa, int B, int Bmod, int S, int d, hipStream_t s);
+                         float* enc, _Float16* enc16, float* coa, int B, int Bmod, int S, int d, hipStream_t s);
 // V2 front end: RoPE -> causal local attention (window, look back one window) -> RoPE at pos+1,
 // written into enc[b][t+1][:].   xseq [B*T][d];  cos/sin tables [>=T+1][e/2], e = d/heads.
 hipError_t launch_local_attention(const float* xseq, const float* cosT, const float* sinT, float* enc,
-                                  int B, int T, int d, int heads, int window, hipStream_t s);
+                                  _Float16* enc16, int B, int T, int d, int heads, int window, hipStream_t s);
+// dst[i] = (fp16) src[i]
+hipError_t launch_convert_f16(const float* src, _Float16* dst, int64_t n, hipStream_t s);
+hipError_t launch_convert_f32(const _Float16* src, float* dst, int64_t n, hipStream_t s);
 // out = u + scale[b]*(c - u)
 hipError_t launch_cfg_blend(const float* c, const float* u, const float* scale, float* out, int B,
                             int64_t per_sample, hipStream_t s);

@@ -1,0 +1,337 @@
+// Persistent fp16-input / fp32-accumulate MFMA GEMM (reduced-precision mode, BASELINE config 5):
+//     C = A * W^T (+ bias, + per-row term R, + per-sample vector V, optional GELU)
+// A [M][K] fp16 row-major activations, W packed fp16 weights [N(pad)][K], both K-contiguous; C fp16 and/or fp32.
+//
+// Same skeleton as gemm2.hip (one 512-thread workgroup per CU walking tiles lid, lid+G, ...; waves 0-3 run
+// ds_read_b128 + MFMA and store their accumulators straight from registers, waves 4-7 only issue LDS-DMA), re-cut
+// for v_mfma_f32_16x16x32_f16, which is 16x the fp32 MFMA rate, so everything around the MFMA had to shrink:
+//   * K slab = 32 halves = ONE MFMA k-step; LDS rows are 64 B, un-padded (an LDS-DMA piece is 1 KiB lane-linear,
+//     so rows cannot be padded); bank conflicts are removed by permuting the four 16-B chunks of a row,
+//     phys = chunk ^ ((-(row >> sh)) & 3), applied on the DMA *source* address and on the fragment read address.
+//     With ds_read_b128's lane groups {0-3,12-15,20-27},{4-11,16-19,28-31} (+32) every group then touches all
+//     64 banks exactly once (MI355X_MICROARCH.md, LDS table);
+//   * a 6-stage ring of 24 KiB stages (128 x 256 tile) keeps three slabs of DMA in flight across the per-slab
+//     barrier (counted s_waitcnt vmcnt, raw s_barrier): a slab is issued four steps (about 2 000 cycles) before
+//     its first read;
+//   * the MFMA runs "swapped": the weight fragment is the A operand and the activation fragment the B operand, so
+//     the accumulator has the output ROW on the lane (lane & 15) and output columns in its registers.  The W rows
+//     are dealt to the lanes as n = q*4*NBW + j*4 + e (q = lane >> 4 of the accumulator, j = column block,
+//     e = register), which makes every lane own 4*NBW CONSECUTIVE output columns of one row: the epilogue is
+//     NBW/2 16-byte stores of packed halves per 16 rows (128 B contiguous per row across the four q groups)
+//     instead of 16*NBW 2-byte stores, and the token-row map / residual terms of the boundary linears are
+//     one division and NBW float4 loads per row;
+//   * the A operand's buffer descriptor carries the exact size, so rows past M read as zeros and are never stored.
+// Summation order per output element is k-slab by k-slab and independent of the tile shape.
+#include "gdx_internal.h"
+
+#include <cstdio>
+#include <cstdlib>
+
+namespace gdx {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+template <int N>
+__device__ __forceinline__ void wait_vm_h() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+// gelu_erf on two values at once (packed fp32 VALU, no transcendental): erf(z) = z * P(2 z^2 / 9 - 1) on |z| <= 3
+// (degree-10 Chebyshev fit, |err| <= 1.2e-6), z clamped to +-3 beyond (1 - erf(3) = 2.2e-5).  |gelu err| <= 2.5e-6
+// for |x| < 4.2 and <= 1.1e-5 * |x| above -- far below the fp16 resolution of the value it is rounded to.
+__device__ __forceinline__ f32x2 gelu2(f32x2 x) {
+    f32x2 z = x * 0.70710678118654752440f;
+    z = f32x2{fminf(fmaxf(z.x, -3.0f), 3.0f), fminf(fmaxf(z.y, -3.0f), 3.0f)};
+    const f32x2 u = z * z * 0.22222222222f - 1.0f;
+    f32x2 pl = u * 1.277365551e-03f + -3.382344944e-03f;
+    pl = pl * u + 5.076731342e-03f;
+    pl = pl * u + -1.096675412e-02f;
+    pl = pl * u + 2.438736657e-02f;
+    pl = pl * u + -4.437220804e-02f;
+    pl = pl * u + 7.247759357e-02f;
+    pl = pl * u + -1.100018414e-01f;
+    pl = pl * u + 1.575016837e-01f;
+    pl = pl * u + -2.288030024e-01f;
+    pl = pl * u + 4.701317549e-01f;
+    const f32x2 h = x * 0.5f;
+    return h + h * (z * pl);
+}
+
+template <int MB, int NBW, int NST>
+__global__ __launch_bounds__(512, 1) void gemmh_kernel(const GemmHParams p, const int ntn, const int ntiles) {
+#if defined(__HIP_DEVICE_COMPILE__)   // the host pass only needs the launch stub (buffer-resource builtins are device-only)
+    constexpr int BM = MB * 16, WN = NBW * 16, BN = WN * 4;
+    constexpr int A_BYTES = BM * 64, W_BYTES = BN * 64, STAGE_BYTES = A_BYTES + W_BYTES;
+    constexpr int A_P = A_BYTES / 1024, P = STAGE_BYTES / 1024;   // 1 KiB DMA pieces (16 rows x 64 B) per slab
+    constexpr int PW = (P + 3) / 4;                               // pieces per loader wave per slab
+    constexpr int SHW = NBW == 4 ? 4 : NBW == 2 ? 3 : 2;          // log2(columns per accumulator q group)
+    constexpr int VM_STEP = (NST - 3) * PW;                       // DMA pieces younger than the slab a step waits for
+    static_assert(NBW == 1 || NBW == 2 || NBW == 4, "NBW must be 1, 2 or 4");
+    static_assert(NST >= 3 && VM_STEP < 64, "ring depth / vmcnt range");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* const bias_lds = reinterpret_cast<float*>(smem + NST * STAGE_BYTES);
+
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid) >> 6;
+    const int lane = tid & 63;
+    const int l15 = lane & 15, lq = lane >> 4;
+    const int G = gridDim.x;
+    int lid;
+    {   // XCD-aware bijective remap (blocks b, b+8, ... share an XCD)
+        const int bid = blockIdx.x, q = G >> 3, r = G & 7, xcd = bid & 7, idx = bid >> 3;
+        lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int my_tiles = lid < ntiles ? (ntiles - lid + G - 1) / G : 0;
+    const int nk = p.K / 32;
+    const int total = my_tiles * nk;                              // even: K % 64 == 0
+    if (total == 0) return;
+
+    if (wave < 4)
+        for (int i = tid; i < p.N; i += 256) bias_lds[i] = p.bias ? p.bias[i] : 0.0f;
+
+    if (wave >= 4) {
+        // ================================================================== loader waves: DMA issue only
+        const auto rsrcA = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(p.A), (short)0, p.a_bytes, 0x00020000);
+        const auto rsrcW = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(p.W), (short)0, p.w_bytes, 0x00020000);
+        int voff[PW];
+#pragma unroll
+        for (int i = 0; i < PW; ++i) {
+            int piece = (wave & 3) + 4 * i;
+            piece = piece < P ? piece : P - 1;                    // surplus issues re-write the last piece (same bytes)
+            const bool isA = piece < A_P;
+            const int row = (isA ? piece : piece - A_P) * 16 + (lane >> 2);
+            const int g = (-(row >> (isA ? 2 : SHW))) & 3;
+            const int chunk = (lane & 3) ^ g;
+            voff[i] = row * (isA ? p.lda : p.ldw) * 2 + chunk * 16;
+        }
+        int ld_tile_i = 0, ld_ks = 0;                             // next slab to issue
+        int ld_m0 = (lid / ntn) * BM, ld_n0 = (lid % ntn) * BN;
+        auto issue = [&](int stage) {                             // exactly PW DMA instructions, no VALU
+            const int a_so = (ld_m0 * p.lda + ld_ks * 32) * 2;
+            const int w_so = (ld_n0 * p.ldw + ld_ks * 32) * 2;
+            char* sb = smem + stage * STAGE_BYTES;
+#pragma unroll
+            for (int i = 0; i < PW; ++i) {
+                int piece = (wave & 3) + 4 * i;
+                piece = piece < P ? piece : P - 1;
+                if (piece < A_P)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcA, (lds_ptr_t)(sb + piece * 1024), 16, voff[i], a_so, 0, 0);
+                else
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcW, (lds_ptr_t)(sb + A_BYTES + (piece - A_P) * 1024), 16,
+                                                             voff[i], w_so, 0, 0);
+            }
+            asm volatile("" ::: "memory");                        // keep the DMA issue where it is (counted waits)
+            if (++ld_ks == nk) {
+                ld_ks = 0;
+                ++ld_tile_i;
+                const int ti = ld_tile_i < my_tiles ? ld_tile_i : my_tiles - 1;   // past the end: harmless re-reads
+                const int tile = lid + ti * G;
+                ld_m0 = (tile / ntn) * BM;
+                ld_n0 = (tile % ntn) * BN;
+            }
+        };
+#pragma unroll
+        for (int s = 0; s < NST - 1; ++s) issue(s);
+        wait_vm_h<VM_STEP>();
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        int wst = NST - 1;
+        for (int g = 0; g < total; ++g) {
+            issue(wst);                                           // slab g+NST-1 -> the stage freed by the last barrier
+            wst = wst == NST - 1 ? 0 : wst + 1;
+            wait_vm_h<VM_STEP>();                                 // slab g+2 has landed
+            asm volatile("s_barrier" ::: "memory");
+        }
+        wait_vm_h<0>();
+        return;
+    }
+
+    // ---- consumer state --------------------------------------------------------------------------------------
+    f32x4 acc[MB][NBW];
+#pragma unroll
+    for (int i = 0; i < MB; ++i)
+#pragma unroll
+        for (int j = 0; j < NBW; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int gq = (-(l15 >> 2)) & 3;
+    const int a_off = l15 * 64 + ((lq ^ gq) * 16);                                   // activation fragment, bytes
+    const int w_off = A_BYTES + (wave * WN + (l15 >> 2) * (4 * NBW) + (l15 & 3)) * 64 + ((lq ^ gq) * 16);
+    f16x8 fa0[MB], fw0[NBW], fa1[MB], fw1[NBW];
+    auto rd = [&](f16x8 (&fa)[MB], f16x8 (&fw)[NBW], int stage) {
+        const char* S = smem + stage * STAGE_BYTES;
+#pragma unroll
+        for (int j = 0; j < NBW; ++j) fw[j] = *reinterpret_cast<const f16x8*>(S + w_off + j * 256);
+#pragma unroll
+        for (int i = 0; i < MB; ++i) fa[i] = *reinterpret_cast<const f16x8*>(S + a_off + i * 1024);
+    };
+    auto mm = [&](const f16x8 (&fa)[MB], const f16x8 (&fw)[NBW]) {
+#pragma unroll
+        for (int i = 0; i < MB; ++i)
+#pragma unroll
+            for (int j = 0; j < NBW; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fw[j], fa[i], acc[i][j], 0, 0, 0);
+    };
+    int ks = 0, stage = 0, tile_i = 0;
+    auto epilogue = [&]() {
+        // accumulator: lane & 15 = output row inside the 16-row block, registers = columns q*4*NBW + j*4 + e
+        const int tile = lid + tile_i * G;
+        ++tile_i;
+        const int m0 = (tile / ntn) * BM, n0 = (tile % ntn) * BN;
+        const int nb = n0 + wave * WN + lq * (4 * NBW);
+        f32x4 bv[NBW];
+#pragma unroll
+        for (int j = 0; j < NBW; ++j) bv[j] = *reinterpret_cast<const f32x4*>(&bias_lds[nb + j * 4]);
+#pragma unroll
+        for (int i = 0; i < MB; ++i) {
+            const int m = m0 + i * 16 + l15;
+            f32x4 v[NBW];
+#pragma unroll
+            for (int j = 0; j < NBW; ++j) {
+                v[j] = acc[i][j] + bv[j];
+                acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+            if (m < p.M) {
+                long ro = m;
+                int bs = 0;
+                if (p.rowmap || p.V) {
+                    bs = m / p.T;
+                    if (p.rowmap) ro = (long)m + bs + 1;
+                }
+                if (p.R) {
+#pragma unroll
+                    for (int j = 0; j < NBW; ++j) v[j] += *reinterpret_cast<const f32x4*>(&p.R[ro * p.ldr + nb + j * 4]);
+                }
+                if (p.V) {
+#pragma unroll
+                    for (int j = 0; j < NBW; ++j) v[j] += *reinterpret_cast<const f32x4*>(&p.V[(long)bs * p.ldv + nb + j * 4]);
+                }
+                if (p.gelu) {
+#pragma unroll
+                    for (int j = 0; j < NBW; ++j) {
+                        const f32x2 lo = gelu2(f32x2{v[j][0], v[j][1]}), hi = gelu2(f32x2{v[j][2], v[j][3]});
+                        v[j] = f32x4{lo.x, lo.y, hi.x, hi.y};
+                    }
+                }
+                if (p.C32) {
+#pragma unroll
+                    for (int j = 0; j < NBW; ++j) *reinterpret_cast<f32x4*>(&p.C32[ro * p.ldc32 + nb + j * 4]) = v[j];
+                }
+                if (p.C16) {
+                    _Float16* cp = p.C16 + ro * p.ldc16 + nb;
+                    if constexpr (NBW == 1) {
+                        *reinterpret_cast<f16x4*>(cp) =
+                            f16x4{(_Float16)v[0][0], (_Float16)v[0][1], (_Float16)v[0][2], (_Float16)v[0][3]};
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < NBW; j += 2)
+                            *reinterpret_cast<f16x8*>(cp + j * 4) =
+                                f16x8{(_Float16)v[j][0],     (_Float16)v[j][1],     (_Float16)v[j][2],     (_Float16)v[j][3],
+                                      (_Float16)v[j + 1][0], (_Float16)v[j + 1][1], (_Float16)v[j + 1][2], (_Float16)v[j + 1][3]};
+                    }
+                }
+            }
+        }
+    };
+
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // slabs 0..2 landed (loaders waited)
+    rd(fa0, fw0, 0);
+    for (int g = 0; g < total; g += 2) {
+        // ---- even step: fragments of slab g are in (fa0, fw0)
+        int nstage = stage == NST - 1 ? 0 : stage + 1;
+        rd(fa1, fw1, nstage);                                     // slab g+1: landed before the last barrier
+        mm(fa0, fw0);
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        stage = nstage;
+        // ---- odd step (nk is even, so a tile always ends on an odd step)
+        nstage = stage == NST - 1 ? 0 : stage + 1;
+        if (g + 2 < total) rd(fa0, fw0, nstage);
+        mm(fa1, fw1);
+        ks += 2;
+        if (ks == nk) {
+            ks = 0;
+            epilogue();
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        stage = nstage;
+    }
+#endif
+}
+
+template <int MB, int NBW, int NST>
+constexpr size_t gh_lds_bytes(int N) {
+    return (size_t)NST * (MB * 16 + NBW * 64) * 64 + (size_t)N * 4;
+}
+
+template <int MB, int NBW, int NST>
+static hipError_t launch_cfg_h(const GemmHParams& p, int num_cus, hipStream_t s) {
+    constexpr int BM = MB * 16, BN = NBW * 64;
+    const size_t lds = gh_lds_bytes<MB, NBW, NST>(p.N);
+    static size_t attr_lds = 0;
+    if (lds > attr_lds) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemmh_kernel<MB, NBW, NST>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr_lds = lds;
+    }
+    const int ntm = (p.M + BM - 1) / BM, ntn = p.N / BN;
+    const int ntiles = ntm * ntn;
+    const int grid = ntiles < num_cus ? ntiles : num_cus;
+    hipLaunchKernelGGL((gemmh_kernel<MB, NBW, NST>), dim3(grid), dim3(512), lds, s, p, ntn, ntiles);
+    return hipGetLastError();
+}
+
+// (MB, NBW, NST): tile = 16*MB rows x 64*NBW columns, NST LDS stages of (16*MB + 64*NBW) * 64 bytes
+#define GH_CONFIGS(X) X(8, 4, 6) X(4, 4, 6) X(8, 2, 6) X(4, 2, 6) X(8, 1, 6) X(4, 1, 6) X(2, 1, 6)
+
+static bool gh_valid(int mb, int nbw, int nst, const GemmHParams& p) {
+    return p.N % (nbw * 64) == 0 && (size_t)nst * (mb * 16 + nbw * 64) * 64 + (size_t)p.N * 4 <= 160 * 1024;
+}
+
+// Estimated cycles: rounds * (K steps * max(MFMA, staging) + epilogue)
+static double gh_cost(int mb, int nbw, int M, int N, int K, int num_cus, bool gelu) {
+    const int BM = mb * 16, BN = nbw * 64;
+    const double tiles = (double)((M + BM - 1) / BM) * (N / BN);
+    const double rounds = (double)(long)((tiles + num_cus - 1) / num_cus);
+    const double mfma = (double)mb * nbw * 16.0;                     // cycles per K step per wave
+    const double mem = (double)(BM + BN) * 64.0 / 24.0;              // staging at ~24 B/clk/CU
+    const double step = (mfma > mem ? mfma : mem) + 60.0;
+    return rounds * ((K / 32) * step + mb * nbw * (gelu ? 160.0 : 30.0) + 600.0);
+}
+
+int gemm2_num_cus();
+
+bool gemmh_supported(const GemmHParams& p) {
+    return p.A && p.W && p.K > 0 && p.K % 64 == 0 && p.N > 0 && p.N % 64 == 0 && p.N <= 8192 && p.lda % 8 == 0 &&
+           p.ldw % 8 == 0 && p.a_bytes > 0 && p.w_bytes > 0 && (!p.C16 || p.ldc16 % 8 == 0) && (!p.C32 || p.ldc32 % 4 == 0) &&
+           (!p.R || p.ldr % 4 == 0) && (!p.V || p.ldv % 4 == 0);
+}
+
+hipError_t launch_gemmh(const GemmHParams& p, hipStream_t s) {
+    if (!gemmh_supported(p)) return hipErrorInvalidValue;
+    const int num_cus = gemm2_num_cus();
+    int best_mb = 0, best_nbw = 0;
+    static int force_mb = -1, force_nbw = -1;
+    if (force_mb < 0) {
+        force_mb = force_nbw = 0;
+        if (const char* e = getenv("GDX_GEMMH_TILE")) sscanf(e, "%d,%d", &force_mb, &force_nbw);
+    }
+    static const bool debug = getenv("GDX_GEMM_DEBUG") != nullptr;
+    double best = 1e30;
+#define X(mb, nbw, nst)                                                           \
+    if (gh_valid(mb, nbw, nst, p)) {                                              \
+        double c = gh_cost(mb, nbw, p.M, p.N, p.K, num_cus, p.gelu != 0);         \
+        if (force_mb == mb && force_nbw == nbw) c = 0.0;                          \
+        if (c < best) { best = c; best_mb = mb; best_nbw = nbw; }                 \
+    }
+    GH_CONFIGS(X)
+#undef X
+    if (!best_mb) return hipErrorNotSupported;
+    if (debug) fprintf(stderr, "[gemmh] M=%d N=%d K=%d -> tile %dx%d\n", p.M, p.N, p.K, best_mb * 16, best_nbw * 64);
+#define X(mb, nbw, nst) \
+    if (best_mb == mb && best_nbw == nbw) return launch_cfg_h<mb, nbw, nst>(p, num_cus, s);
+    GH_CONFIGS(X)
+#undef X
+    return hipErrorInvalidValue;
+}
+
+}  // namespace gdx

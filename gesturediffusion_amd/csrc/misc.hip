@@ -6,6 +6,7 @@
 namespace gdx {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
@@ -22,7 +23,8 @@ template <int VPL>   // float4 per lane: d = 256 * VPL
 __global__ __launch_bounds__(256) void layernorm_vec_kernel(const float* __restrict__ x, const float* __restrict__ res,
                                                              const float* __restrict__ g,
                                                              const float* __restrict__ bta, float* __restrict__ out,
-                                                             int rows, int d, int compact_S) {
+                                                             _Float16* __restrict__ out16, int rows, int d,
+                                                             int compact_S) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (row >= rows) return;
@@ -53,6 +55,7 @@ __global__ __launch_bounds__(256) void layernorm_vec_kernel(const float* __restr
         }
     const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)d + 1e-5f);
     f32x4* op = reinterpret_cast<f32x4*>(out + orow * d);
+    f16x4* hp = reinterpret_cast<f16x4*>(out16 + orow * d);
     const f32x4* gp = reinterpret_cast<const f32x4*>(g);
     const f32x4* bp = reinterpret_cast<const f32x4*>(bta);
 #pragma unroll
@@ -61,7 +64,8 @@ __global__ __launch_bounds__(256) void layernorm_vec_kernel(const float* __restr
         f32x4 r;
 #pragma unroll
         for (int e = 0; e < 4; ++e) r[e] = (v[i][e] - mean) * rstd * gg[e] + bb[e];
-        op[lane + 64 * i] = r;
+        if (out) op[lane + 64 * i] = r;
+        if (out16) hp[lane + 64 * i] = f16x4{(_Float16)r[0], (_Float16)r[1], (_Float16)r[2], (_Float16)r[3]};
     }
 }
 
@@ -69,7 +73,8 @@ __global__ __launch_bounds__(256) void layernorm_vec_kernel(const float* __restr
 __global__ __launch_bounds__(256) void layernorm_gen_kernel(const float* __restrict__ x, const float* __restrict__ res,
                                                              const float* __restrict__ g,
                                                              const float* __restrict__ bta, float* __restrict__ out,
-                                                             int rows, int d, int compact_S) {
+                                                             _Float16* __restrict__ out16, int rows, int d,
+                                                             int compact_S) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (row >= rows) return;
@@ -90,21 +95,24 @@ __global__ __launch_bounds__(256) void layernorm_gen_kernel(const float* __restr
         q += c * c;
     }
     const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)d + 1e-5f);
-    for (int e = lane; e < d; e += 64)
-        out[orow * d + e] = ((res ? xp[e] + rp[e] : xp[e]) - mean) * rstd * g[e] + bta[e];
+    for (int e = lane; e < d; e += 64) {
+        const float r = ((res ? xp[e] + rp[e] : xp[e]) - mean) * rstd * g[e] + bta[e];
+        if (out) out[orow * d + e] = r;
+        if (out16) out16[orow * d + e] = (_Float16)r;
+    }
 }
 
 hipError_t launch_layernorm(const float* x, const float* res, const float* gamma, const float* beta, float* out,
-                            int rows, int d, int compact_S, hipStream_t s) {
+                            _Float16* out16, int rows, int d, int compact_S, hipStream_t s) {
     const dim3 grid((rows + 3) / 4), block(256);
     if (d == 512)
-        hipLaunchKernelGGL(layernorm_vec_kernel<2>, grid, block, 0, s, x, res, gamma, beta, out, rows, d, compact_S);
+        hipLaunchKernelGGL(layernorm_vec_kernel<2>, grid, block, 0, s, x, res, gamma, beta, out, out16, rows, d, compact_S);
     else if (d == 1024)
-        hipLaunchKernelGGL(layernorm_vec_kernel<4>, grid, block, 0, s, x, res, gamma, beta, out, rows, d, compact_S);
+        hipLaunchKernelGGL(layernorm_vec_kernel<4>, grid, block, 0, s, x, res, gamma, beta, out, out16, rows, d, compact_S);
     else if (d == 256)
-        hipLaunchKernelGGL(layernorm_vec_kernel<1>, grid, block, 0, s, x, res, gamma, beta, out, rows, d, compact_S);
+        hipLaunchKernelGGL(layernorm_vec_kernel<1>, grid, block, 0, s, x, res, gamma, beta, out, out16, rows, d, compact_S);
     else
-        hipLaunchKernelGGL(layernorm_gen_kernel, grid, block, 0, s, x, res, gamma, beta, out, rows, d, compact_S);
+        hipLaunchKernelGGL(layernorm_gen_kernel, grid, block, 0, s, x, res, gamma, beta, out, out16, rows, d, compact_S);
     return hipGetLastError();
 }
 
@@ -114,7 +122,8 @@ hipError_t launch_layernorm(const float* x, const float* res, const float* gamma
 // config 2: a few microseconds, and they let both boundary linears run on the persistent GEMM.
 //   in : x [Bsrc, J, T]  -> xt [(b*T + t)*ldx + j], b < B (source sample b % Bsrc), columns j >= J zeroed
 //   out: yt [(b*T + t)*ldy + j] -> y [(b*J + j)*T + t]
-__global__ __launch_bounds__(256) void transpose_in_kernel(const float* __restrict__ x, float* __restrict__ xt, int Bsrc,
+template <typename OutT>
+__global__ __launch_bounds__(256) void transpose_in_kernel(const float* __restrict__ x, OutT* __restrict__ xt, int Bsrc,
                                                            int J, int T, int ldx) {
     __shared__ float tile[32][33];
     const int b = blockIdx.z, t0 = blockIdx.x * 32, j0 = blockIdx.y * 32;
@@ -129,7 +138,7 @@ __global__ __launch_bounds__(256) void transpose_in_kernel(const float* __restri
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int t = t0 + ty + 8 * r, j = j0 + tx;
-        if (t < T && j < ldx) xt[((long)b * T + t) * ldx + j] = tile[tx][ty + 8 * r];
+        if (t < T && j < ldx) xt[((long)b * T + t) * ldx + j] = (OutT)tile[tx][ty + 8 * r];
     }
 }
 
@@ -153,7 +162,13 @@ __global__ __launch_bounds__(256) void transpose_out_kernel(const float* __restr
 
 hipError_t launch_transpose_in(const float* x, float* xt, int B, int Bsrc, int J, int T, int ldx, hipStream_t s) {
     const dim3 grid((T + 31) / 32, (ldx + 31) / 32, B);
-    hipLaunchKernelGGL(transpose_in_kernel, grid, dim3(256), 0, s, x, xt, Bsrc, J, T, ldx);
+    hipLaunchKernelGGL(transpose_in_kernel<float>, grid, dim3(256), 0, s, x, xt, Bsrc, J, T, ldx);
+    return hipGetLastError();
+}
+
+hipError_t launch_transpose_in_f16(const float* x, _Float16* xt, int B, int Bsrc, int J, int T, int ldx, hipStream_t s) {
+    const dim3 grid((T + 31) / 32, (ldx + 31) / 32, B);
+    hipLaunchKernelGGL(transpose_in_kernel<_Float16>, grid, dim3(256), 0, s, x, xt, Bsrc, J, T, ldx);
     return hipGetLastError();
 }
 
@@ -240,8 +255,8 @@ hipError_t launch_mfcc_project(const float* mfcc, const float* W, int ldw, const
 
 // conditioning token (model/mdm_old.py:94-111: emb_t + emb_seed, then + pe[0]; model/mdm.py:154-160,197)
 __global__ void token0_kernel(const float* __restrict__ temb, int tstride, const float* __restrict__ seed_emb,
-                              const float* __restrict__ pe0, float* __restrict__ enc, float* __restrict__ coa, int B,
-                              int Bmod, int S, int d) {
+                              const float* __restrict__ pe0, float* __restrict__ enc, _Float16* __restrict__ enc16,
+                              float* __restrict__ coa, int B, int Bmod, int S, int d) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= B * d) return;
     const int b = i / d, n = i % d;
@@ -249,12 +264,13 @@ __global__ void token0_kernel(const float* __restrict__ temb, int tstride, const
     if (coa) coa[i] = v;
     if (pe0) v += pe0[n];
     enc[(long)b * S * d + n] = v;
+    if (enc16) enc16[(long)b * S * d + n] = (_Float16)v;
 }
 
 hipError_t launch_token0(const float* temb, int tstride, const float* seed_emb, const float* pe0, float* enc,
-                         float* coa, int B, int Bmod, int S, int d, hipStream_t s) {
+                         _Float16* enc16, float* coa, int B, int Bmod, int S, int d, hipStream_t s) {
     hipLaunchKernelGGL(token0_kernel, dim3((B * d + 255) / 256), dim3(256), 0, s, temb, tstride, seed_emb, pe0, enc,
-                       coa, B, Bmod, S, d);
+                       enc16, coa, B, Bmod, S, d);
     return hipGetLastError();
 }
 
@@ -269,7 +285,8 @@ hipError_t launch_token0(const float* temb, int tstride, const float* seed_emb, 
 __global__ __launch_bounds__(64) void local_attention_kernel(const float* __restrict__ xseq,
                                                              const float* __restrict__ cosT,
                                                              const float* __restrict__ sinT, float* __restrict__ enc,
-                                                             int T, int d, int heads, int window) {
+                                                             _Float16* __restrict__ enc16, int T, int d, int heads,
+                                                             int window) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int e = d / heads, half = e >> 1;
     const int nwin = T / window;
@@ -336,16 +353,47 @@ __global__ __launch_bounds__(64) void local_attention_kernel(const float* __rest
         const float x = ob[qi * es + c];
         const float rot = c < half ? -ob[qi * es + c + half] : ob[qi * es + c - half];
         const int f = c < half ? c : c - half;
-        eb[(long)pos * d + c] = x * cosT[pos * half + f] + rot * sinT[pos * half + f];
+        const float v = x * cosT[pos * half + f] + rot * sinT[pos * half + f];
+        eb[(long)pos * d + c] = v;
+        if (enc16) enc16[((long)b * (T + 1) + pos) * d + head * e + c] = (_Float16)v;
     }
 }
 
-hipError_t launch_local_attention(const float* xseq, const float* cosT, const float* sinT, float* enc, int B, int T,
-                                  int d, int heads, int window, hipStream_t s) {
+hipError_t launch_local_attention(const float* xseq, const float* cosT, const float* sinT, float* enc,
+                                  _Float16* enc16, int B, int T, int d, int heads, int window, hipStream_t s) {
     const int e = d / heads;
     const size_t lds = (size_t)(2 * window * (e + 1) + window * 2 * window + window * (e + 1)) * sizeof(float);
     const dim3 grid(B * heads * (T / window)), block(64);
-    hipLaunchKernelGGL(local_attention_kernel, grid, block, lds, s, xseq, cosT, sinT, enc, T, d, heads, window);
+    hipLaunchKernelGGL(local_attention_kernel, grid, block, lds, s, xseq, cosT, sinT, enc, enc16, T, d, heads, window);
+    return hipGetLastError();
+}
+
+__global__ void convert_f16_kernel(const float* __restrict__ src, _Float16* __restrict__ dst, int64_t n) {
+    const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (i + 3 < n) {
+        const float4 v = *reinterpret_cast<const float4*>(src + i);
+        typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+        *reinterpret_cast<h4*>(dst + i) = h4{(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
+    } else {
+        for (int64_t k = i; k < n; ++k) dst[k] = (_Float16)src[k];
+    }
+}
+
+__global__ void convert_f32_kernel(const _Float16* __restrict__ src, float* __restrict__ dst, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = (float)src[i];
+}
+
+hipError_t launch_convert_f32(const _Float16* src, float* dst, int64_t n, hipStream_t s) {
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(convert_f32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, src, dst, n);
+    return hipGetLastError();
+}
+
+hipError_t launch_convert_f16(const float* src, _Float16* dst, int64_t n, hipStream_t s) {
+    if (n <= 0) return hipSuccess;
+    const int64_t nth = (n + 3) / 4;
+    hipLaunchKernelGGL(convert_f16_kernel, dim3((unsigned)((nth + 255) / 256)), dim3(256), 0, s, src, dst, n);
     return hipGetLastError();
 }
 

@@ -35,14 +35,22 @@ def f32c(t, what):
     return t.contiguous()
 
 
+# gdx.h GDX_DTYPE_*: "fp32" = exact fp32 MFMA everywhere (default); "fp16" = fp16 GEMM operands, fp32 accumulate
+COMPUTE_DTYPES = {"fp32": 0, "fp16": 1}
+
+
 class Engine:
     """One libgdx handle = one model instance on one device/stream."""
 
-    def __init__(self, arch, njoints, latent_dim, ff_size, num_layers, num_heads, seed_poses, cl_head=8, window=10):
+    def __init__(self, arch, njoints, latent_dim, ff_size, num_layers, num_heads, seed_poses, cl_head=8, window=10,
+                 compute_dtype="fp32"):
         self.lib = _lib.load()
+        if compute_dtype not in COMPUTE_DTYPES:
+            raise ValueError(f"compute_dtype must be one of {sorted(COMPUTE_DTYPES)}, got {compute_dtype!r}")
+        self.compute_dtype = compute_dtype
         self.cfg = _lib.Config(arch=arch, njoints=njoints, latent_dim=latent_dim, ff_size=ff_size,
                                num_layers=num_layers, num_heads=num_heads, seed_poses=seed_poses, mfcc_dim=MFCC_DIM,
-                               cl_head=cl_head, window=window)
+                               cl_head=cl_head, window=window, compute_dtype=COMPUTE_DTYPES[compute_dtype])
         self.handle = C.c_void_p()
         _lib.check(self.lib.gdx_create(C.byref(self.cfg), C.byref(self.handle)), self.lib)
         self.device = None

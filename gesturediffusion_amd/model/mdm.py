@@ -8,6 +8,7 @@ only HOLD parameters; all arithmetic runs in libgdx.so (hand-written HIP for gfx
 or a missing library raises.
 """
 import math
+import os
 
 import numpy as np
 import torch
@@ -152,9 +153,12 @@ class _NativeDenoiser(nn.Module):
         named = self._engine_tensors()
         key = tuple((k, v.data_ptr(), v._version) for k, v in named.items())
         eng = self.__dict__.get("_eng")
+        dtype = getattr(self, "compute_dtype", None) or os.environ.get("GDX_COMPUTE_DTYPE", "fp32")
+        if eng is not None and eng.compute_dtype != dtype:
+            eng = None
         if eng is None:
             eng = Engine(self._arch, self.input_feats, self.latent_dim, self.ff_size, self.num_layers, self.num_heads,
-                         self.seed_poses, cl_head=getattr(self, "cl_head", 8), window=10)
+                         self.seed_poses, cl_head=getattr(self, "cl_head", 8), window=10, compute_dtype=dtype)
             self.__dict__["_eng"] = eng
             self.__dict__["_eng_key"] = None
         if self.__dict__["_eng_key"] != key:
@@ -220,6 +224,7 @@ class MDM(_NativeDenoiser):
             raise NotImplementedError("use_text needs CLIP weights (network download); not available")
 
         self.seed_poses = kargs.get("seed_poses", 0)
+        self.compute_dtype = kargs.get("compute_dtype", None)   # additive: "fp32" (default) | "fp16" (engine.COMPUTE_DTYPES)
         if self.seed_poses > 0:
             self.seed_pose_encoder = SeedPoseEncoder(njoints, self.seed_poses, latent_dim)
 

@@ -31,6 +31,7 @@ class MDM_Old(_NativeDenoiser):
 
         self.cond_mask_prob = kargs.get("cond_mask_prob", 0.0)
         self.seed_poses = kargs.get("seed_poses", 0)
+        self.compute_dtype = kargs.get("compute_dtype", None)   # additive: "fp32" (default) | "fp16"
         assert self.seed_poses > 0                                   # model/mdm_old.py:32
         self.seed_pose_encoder = SeedPoseEncoder(njoints, self.seed_poses, latent_dim)
         self.mfcc_dim = 26

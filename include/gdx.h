@@ -33,6 +33,10 @@ enum { GDX_COND = 0,          /* y without 'uncond'                     (model/m
        GDX_UNCOND = 1,        /* y['uncond'] = True: seed poses zeroed  (model/mdm.py:127,242-250) */
        GDX_CFG = 2 };         /* both passes + blend                    (model/cfg_sampler.py:23-28) */
 
+enum { GDX_DTYPE_F32 = 0,     /* every GEMM on the exact fp32 MFMA (default; parity tolerance of the fp32 path) */
+       GDX_DTYPE_F16 = 1 };   /* fp16 MFMA operands (weights + activations), fp32 accumulate / residual stream /
+                                 LayerNorm / softmax: BASELINE config 5's reduced-precision mode */
+
 enum { GDX_SAMPLER_P = 0,     /* p_sample      diffusion/gaussian_diffusion.py:496-548 */
        GDX_SAMPLER_DDIM = 1 };/* ddim_sample   diffusion/gaussian_diffusion.py:732-782 */
 
@@ -49,6 +53,8 @@ typedef struct {
     int32_t mfcc_dim;    /* 26 (model/mdm.py:57) */
     int32_t cl_head;     /* 8  (model/mdm.py:71), V2 only */
     int32_t window;      /* 10 (model/mdm.py:75), V2 only */
+    int32_t compute_dtype;   /* GDX_DTYPE_*.  The reference samples in fp32 only (its `use_fp16` is a deprecated
+                                trainer switch, train/training_loop.py:43); fp16 is this library's additive mode */
 } gdx_config_t;
 
 /* ---- lifetime ------------------------------------------------------------------------- */
@@ -181,6 +187,17 @@ int gdx_bench_gemm(int32_t M, int32_t N, int32_t K, int32_t epi, int32_t iters, 
  * 2 = attention2.hip where supported). */
 int gdx_bench_attention(int32_t B, int32_t S, int32_t H, int32_t d, int32_t version, int32_t iters,
                         float* avg_us, void* stream);
+/* ---- reduced-precision building blocks (tests / measurement) ---------------------------- */
+/* out = act(A W^T + bias) through the fp16-input / fp32-accumulate MFMA GEMM of the fp16 mode
+ * (csrc/gemmh.hip): A [M][K], W [N][K], bias [N] or NULL are fp32 device arrays that the call
+ * converts to fp16 (weights are packed exactly as gdx_set_weight packs them); C32 [M][N] receives
+ * the fp32 epilogue output and/or C16 [M][N] the fp16-rounded output widened back to fp32 (either
+ * may be NULL).  K % 64 == 0, N % 64 == 0.  Synchronises the stream (scratch is freed on return). */
+int gdx_linear_f16(const float* A, const float* W, const float* bias, float* C32, float* C16,
+                   int32_t M, int32_t N, int32_t K, int32_t gelu, void* stream);
+/* Time `iters` launches of the fp16 GEMM on scratch operands filled with N(0,1). */
+int gdx_bench_gemm_f16(int32_t M, int32_t N, int32_t K, int32_t gelu, int32_t iters, float* avg_us,
+                       void* stream);
 /* Algorithmic FLOPs of one forward at the prepared shape (SURVEY.md 8d formula). */
 int gdx_forward_flops(gdx_handle_t h, int32_t mode, double* flops);
 
