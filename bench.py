@@ -29,6 +29,7 @@ import torch.distributed as dist  # noqa: E402
 
 LOOP_STEPS = 1000
 F32_MFMA_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD
+F16_MFMA_PEAK_TFLOPS = 2500.0    # MI355X_MICROARCH.md: dense fp16 / bf16 MFMA (v_mfma_f32_16x16x32_f16)
 
 
 def log(msg):
@@ -119,6 +120,8 @@ def main():
     ap.add_argument("--layers", type=int, default=8)
     ap.add_argument("--cfg", action="store_true", help="ClassifierFreeSampleModel (cond+uncond double batch)")
     ap.add_argument("--sampler", default="p", choices=["p", "ddim"])
+    ap.add_argument("--dtype", default="fp32", choices=["fp32", "fp16"],
+                    help="fp32: exact fp32 MFMA (BASELINE's headline path); fp16: fp16 MFMA operands, fp32 accumulate (config 5)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=24)
     args = ap.parse_args()
@@ -134,6 +137,7 @@ def main():
     B, J = args.batch, args.njoints
 
     model, cfg, sd = build_model(args.arch, J, args.latent_dim, args.layers, device)
+    model.compute_dtype = args.dtype
     inner = model
     if args.cfg:
         from gesturediffusion_amd.model.cfg_sampler import ClassifierFreeSampleModel
@@ -197,18 +201,22 @@ def main():
         gemm_us, gemm_launches = eng.profile_end()
         gemm_flops = 2.0 * N * d * ff
         traffic, traffic_src = None, None
+        f16_mode = args.dtype == "fp16"
         pmc = os.path.join(REPO, "profiles", "r01b_pmc_ffn1_traffic.json")
-        if os.path.exists(pmc) and not args.cfg and (B, T, d, args.arch) == (64, 196, 512, "mdm_old"):
+        if os.path.exists(pmc) and not args.cfg and not f16_mode and (B, T, d, args.arch) == (64, 196, 512, "mdm_old"):
             traffic = json.load(open(pmc))["hbm_bytes_per_launch"]     # PMC passes cannot run inside this process
             traffic_src = "profiles/r01b_pmc_ffn1_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this bench)"
         achieved = gemm_flops / (gemm_us * 1e-6) / 1e12
+        f16 = args.dtype == "fp16"
+        peak = F16_MFMA_PEAK_TFLOPS if f16 else F32_MFMA_PEAK_TFLOPS
         rec = {
             "metric": "denoised motion frames/sec (1000-step p_sample_loop, B=64, T=196, d=512)",
             "value": round(frames_per_sec, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None, "dtype": "f16 (fp32 accumulate)" if f16 else "f32",
+            "data": "synthetic",
             "config": {
-                "workload": f"BASELINE config 2: {'MDM_Old (V1 encoder-only topology)' if args.arch == 'mdm_old' else 'MDM (V2)'}"
+                "workload": f"BASELINE config {5 if args.latent_dim == 1024 else 2}: {'MDM_Old (V1 encoder-only topology)' if args.arch == 'mdm_old' else 'MDM (V2)'}"
                             f" J={J} d={args.latent_dim} ff=1024 L={args.layers} H=4, "
                             f"{LOOP_STEPS}-step {'p_sample_loop' if args.sampler == 'p' else 'ddim_sample_loop'}"
                             f"{' + CFG' if args.cfg else ''}, batch {B}/GPU x {T} frames, random weights, Philox noise",
@@ -220,12 +228,14 @@ def main():
             "loop_seconds": round(ms_per_step * LOOP_STEPS * 1e-3, 3),
             "frame_steps_per_sec": round(world * B * T / (ms_per_step * 1e-3), 1),
             "step_tflops": round(world * flops_step / (ms_per_step * 1e-3) / 1e12, 2),
-            "step_frac_of_f32_mfma_peak": round(flops_step / (ms_per_step * 1e-3) / 1e12 / F32_MFMA_PEAK_TFLOPS, 4),
-            "roofline": {"bound": "mfma", "kernel": "gemm4_kernel (gemm2.hip), FFN linear1 + bias + GELU, "
+            ("step_frac_of_f16_mfma_peak" if f16 else "step_frac_of_f32_mfma_peak"):
+                round(flops_step / (ms_per_step * 1e-3) / 1e12 / peak, 4),
+            "roofline": {"bound": "mfma", "kernel": ("gemmh_kernel (gemmh.hip)" if f16 else "gemm4_kernel (gemm2.hip)") +
+                                                    ", FFN linear1 + bias + GELU, "
                                                     f"M={N} N={ff} K={d}; HIP events on the launch stream around "
                                                     f"{gemm_launches} launches inside the timed loop",
-                         "achieved": round(achieved, 2), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved / F32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
+                         "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
+                         "frac": round(achieved / peak, 4), "traffic": traffic,
                          "traffic_source": traffic_src,
                          "avg_launch_us": round(gemm_us, 2), "flops_per_launch": gemm_flops},
         }

@@ -80,6 +80,7 @@ struct gdx_model {
     float *rope_cos = nullptr, *rope_sin = nullptr; int rope_rows = 0;
     // workspace (sized for 2*B samples so that CFG runs as one double batch)
     int B = 0, T = 0, S = 0;
+    long rows_alloc = 0;              // rows of the [2B*S + pad] token buffers
     bool cond_set = false;
     float *xa = nullptr, *xb = nullptr, *qkv = nullptr, *ctx = nullptr, *tmp = nullptr, *ffb = nullptr;
     float *emb_pose = nullptr, *xseq = nullptr, *addend = nullptr;
@@ -342,6 +343,7 @@ extern "C" int gdx_prepare(gdx_handle_t h, int32_t batch, int32_t frames) {
     h->B = batch; h->T = frames; h->S = frames + 1; h->cond_set = false;
     // +128 rows: the persistent GEMM reads / stores whole tiles past the last logical row (gemm2.hip)
     const size_t B2 = 2 * (size_t)batch, N = B2 * h->S + 128, d = h->d;
+    h->rows_alloc = (long)N;
     // zero-filled: the padding rows are read by whole-tile GEMMs / K-V tiles and must stay finite
     auto A = [&](float** p, size_t n) {
         if (dev_alloc(h->ws_allocs, (void**)p, n * sizeof(float))) return -1;
@@ -557,13 +559,9 @@ static int forward_core_f16(gdx_model* h, const float* x, const float* temb, int
         HIPCHK(hipMemcpyAsync(h->taps[0], h->xa, sizeof(float) * (size_t)N * d, hipMemcpyDeviceToDevice, s));
     for (int l = 0; l < h->L; ++l) {
         const Layer& ly = h->layers[l];
-        if (gemm_f16(h->xa16, d, ly.qkv, ly.qkv.bias, nullptr, 0, nullptr, 0, h->qkv, 3 * d, nullptr, 0, N, 3 * d, T, 0, 0, s))
+        if (gemm_f16(h->xa16, d, ly.qkv, ly.qkv.bias, nullptr, 0, nullptr, 0, nullptr, 0, h->qkv16, 3 * d, N, 3 * d, T, 0, 0, s))
             return -1;
-        if (attention2_supported(S, h->H, d))
-            HIPCHK(launch_attention2(h->qkv, h->ctx, Beff, S, h->H, d, s));
-        else
-            HIPCHK(launch_attention(h->qkv, h->ctx, Beff, S, h->H, d, s));
-        HIPCHK(launch_convert_f16(h->ctx, h->ctx16, (int64_t)N * d, s));
+        HIPCHK(launch_attentionh(h->qkv16, h->ctx16, Beff, S, h->H, d, h->rows_alloc, s));
         if (gemm_f16(h->ctx16, d, ly.out, ly.out.bias, nullptr, 0, nullptr, 0, h->tmp, d, nullptr, 0, N, d, T, 0, 0, s)) return -1;
         HIPCHK(launch_layernorm(h->tmp, h->xa, ly.g1, ly.b1, h->xb, h->xb16, N, d, 0, s));
         const bool stamp = h->prof && h->prof_used + 2 <= h->prof_ev.size();
@@ -827,6 +825,26 @@ extern "C" int gdx_linear_f16(const float* A, const float* W, const float* bias,
     return rc;
 }
 
+extern "C" int gdx_attention_f16(const float* qkv, float* ctx, int32_t B, int32_t S, int32_t H, int32_t d, void* stream) {
+    if (!qkv || !ctx || B <= 0 || S <= 0 || H <= 0 || d <= 0 || d % H || !attentionh_supported(S, H, d))
+        return fail("gdx_attention_f16: bad argument / unsupported shape");
+    hipStream_t s = (hipStream_t)stream;
+    const size_t rows = (size_t)B * S;
+    _Float16 *q16 = nullptr, *c16 = nullptr;
+    std::vector<void*> pool;
+    int rc = 0;
+    if (dev_alloc(pool, (void**)&q16, 2 * rows * 3 * d) || dev_alloc(pool, (void**)&c16, 2 * rows * d)) rc = -1;
+    if (!rc && launch_convert_f16(qkv, q16, (int64_t)rows * 3 * d, s) != hipSuccess) rc = fail("gdx_attention_f16: convert failed");
+    if (!rc) {
+        hipError_t e = launch_attentionh(q16, c16, B, S, H, d, (long)rows, s);
+        if (e != hipSuccess) rc = fail(std::string("launch_attentionh: ") + hipGetErrorString(e));
+    }
+    if (!rc && launch_convert_f32(c16, ctx, (int64_t)rows * d, s) != hipSuccess) rc = fail("gdx_attention_f16: convert failed");
+    (void)hipStreamSynchronize(s);
+    free_pool(pool);
+    return rc;
+}
+
 extern "C" int gdx_bench_gemm_f16(int32_t M, int32_t N, int32_t K, int32_t gelu, int32_t iters, float* avg_us, void* stream) {
     if (!avg_us || M <= 0 || N <= 0 || K <= 0 || K % 64 || N % 64 || iters <= 0) return fail("gdx_bench_gemm_f16: bad argument");
     hipStream_t s = (hipStream_t)stream;
@@ -883,7 +901,17 @@ extern "C" int gdx_bench_attention(int32_t B, int32_t S, int32_t H, int32_t d, i
         return -1;
     }
     HIPCHK(gdx_randn(qkv, 1, (int64_t)rows * 3 * d, 5, 0, 0, stream) ? hipErrorUnknown : hipSuccess);
+    _Float16 *qkv16 = nullptr, *ctx16 = nullptr;
+    if (version == 3) {
+        if (!attentionh_supported(S, H, d)) { free_pool(pool); return fail("gdx_bench_attention: shape not supported by the fp16 kernel"); }
+        if (dev_alloc(pool, (void**)&qkv16, 2 * rows * 3 * d) || dev_alloc(pool, (void**)&ctx16, 2 * rows * d)) {
+            free_pool(pool);
+            return -1;
+        }
+        HIPCHK(launch_convert_f16(qkv, qkv16, (int64_t)rows * 3 * d, s));
+    }
     auto run = [&]() -> hipError_t {
+        if (version == 3) return launch_attentionh(qkv16, ctx16, B, S, H, d, (long)rows, s);
         if (version == 2 && attention2_supported(S, H, d)) return launch_attention2(qkv, ctx, B, S, H, d, s);
         return launch_attention(qkv, ctx, B, S, H, d, s);
     };

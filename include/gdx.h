@@ -184,7 +184,7 @@ int gdx_profile_end(gdx_handle_t h, float* avg_us, int32_t* launches);
  * (0 bias, 1 bias+GELU, 2 bias+residual) on scratch buffers filled with N(0,1). */
 int gdx_bench_gemm(int32_t M, int32_t N, int32_t K, int32_t epi, int32_t iters, float* avg_us, void* stream);
 /* Time `iters` launches of the self-attention core on scratch qkv [B*S][3d] (version 1 = attention.hip,
- * 2 = attention2.hip where supported). */
+ * 2 = attention2.hip where supported, 3 = the fp16 kernel attentionh.hip). */
 int gdx_bench_attention(int32_t B, int32_t S, int32_t H, int32_t d, int32_t version, int32_t iters,
                         float* avg_us, void* stream);
 /* ---- reduced-precision building blocks (tests / measurement) ---------------------------- */
@@ -195,6 +195,10 @@ int gdx_bench_attention(int32_t B, int32_t S, int32_t H, int32_t d, int32_t vers
  * may be NULL).  K % 64 == 0, N % 64 == 0.  Synchronises the stream (scratch is freed on return). */
 int gdx_linear_f16(const float* A, const float* W, const float* bias, float* C32, float* C16,
                    int32_t M, int32_t N, int32_t K, int32_t gelu, void* stream);
+/* ctx = softmax(Q K^T / sqrt(hd)) V per (sample, head) through the fp16 attention kernel
+ * (csrc/attentionh.hip): qkv [B*S][3d] and ctx [B*S][d] are fp32 device arrays converted to / from
+ * fp16 by the call.  head_dim = d / H in {64, 128, 256}.  Synchronises the stream. */
+int gdx_attention_f16(const float* qkv, float* ctx, int32_t B, int32_t S, int32_t H, int32_t d, void* stream);
 /* Time `iters` launches of the fp16 GEMM on scratch operands filled with N(0,1). */
 int gdx_bench_gemm_f16(int32_t M, int32_t N, int32_t K, int32_t gelu, int32_t iters, float* avg_us,
                        void* stream);
