@@ -12,7 +12,8 @@
 //   * O^T += V^T P^T: the A operand needs V column-wise; V stays row-major in LDS (as it comes from HBM) and is read
 //     with ds_read_b64_tr_b16 (hardware transpose: two reads = 8 keys x 16 head-dim columns per lane group);
 //   * LDS rows are un-padded (LDS-DMA is lane-linear); the 16-byte chunks of a row are permuted,
-//     phys = chunk ^ f(row), f = (row & 7) << 1 (rows of >= 256 B) or ((row >> 1) & 3) << 1 (128-B rows), on the DMA
+//     phys = chunk ^ f(row), f = (row & 7) << 1 (rows of >= 256 B), ((row >> 1) & 3) << 1 (128-B rows) or
+//     ((row >> 2) & 1) << 1 (64-B rows), on the DMA
 //     source address and on both kinds of read: every ds_read_b128 lane group and every 32-lane half of a
 //     transposed read then covers all 64 banks exactly once;
 //   * deferred max in the log2 domain: the reference value is raised (cross-lane shuffles + O rescale) only when a
@@ -54,7 +55,7 @@ __global__ __launch_bounds__(512, 1) void attentionh_kernel(const _Float16* __re
     constexpr int NKS = HD / 32;                 // MFMA k-steps along head_dim (QK^T)
     constexpr int NNB = HD / 16;                 // 16-wide head-dim blocks (PV)
     constexpr float RESCALE_THR = 8.0f;          // log2 units
-    static_assert(HD == 64 || HD == 128 || HD == 256, "head_dim");
+    static_assert(HD == 32 || HD == 64 || HD == 128 || HD == 256, "head_dim");
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -69,7 +70,7 @@ __global__ __launch_bounds__(512, 1) void attentionh_kernel(const _Float16* __re
     const int qb_lo = (int)((long)ci * nqb / nchunk), qb_hi = (int)((long)(ci + 1) * nqb / nchunk);
     const int ntiles = (S + 31) / 32;
 
-    auto fswz = [](int row) { return HD == 64 ? ((row >> 1) & 3) << 1 : (row & 7) << 1; };
+    auto fswz = [](int row) { return HD == 32 ? ((row >> 2) & 1) << 1 : HD == 64 ? ((row >> 1) & 3) << 1 : (row & 7) << 1; };
 
     if (wave >= 4) {
         // ================================================================== loader waves: LDS-DMA of K/V tiles
@@ -262,7 +263,7 @@ static hipError_t launch_ah(const _Float16* qkv, _Float16* ctx, int B, int S, in
 
 bool attentionh_supported(int S, int H, int d) {
     const int hd = d / H;
-    return (hd == 64 || hd == 128 || hd == 256) && d % 8 == 0 && S >= 1;
+    return (hd == 32 || hd == 64 || hd == 128 || hd == 256) && d % 8 == 0 && S >= 1;
 }
 
 // qkv_rows: rows of the qkv buffer that are readable (>= B*S); reads past them return zeros
@@ -273,6 +274,7 @@ hipError_t launch_attentionh(const _Float16* qkv, _Float16* ctx, int B, int S, i
     if (hd == 256) return launch_ah<256, 2>(qkv, ctx, B, S, H, d, bytes, s);
     if (hd == 128) return launch_ah<128, 2>(qkv, ctx, B, S, H, d, bytes, s);
     if (hd == 64) return launch_ah<64, 2>(qkv, ctx, B, S, H, d, bytes, s);
+    if (hd == 32) return launch_ah<32, 2>(qkv, ctx, B, S, H, d, bytes, s);
     return hipErrorInvalidValue;
 }
 

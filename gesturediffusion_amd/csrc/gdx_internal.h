@@ -64,7 +64,7 @@ hipError_t launch_attention(const float* qkv, float* ctx, int B, int S, int H, i
 bool attention2_supported(int S, int H, int d);
 hipError_t launch_attention2(const float* qkv, float* ctx, int B, int S, int H, int d, hipStream_t s);
 
-// fp16 mode (attentionh.hip): qkv / ctx in halves, head_dim 64/128/256, any S; qkv_rows = readable rows of qkv
+// fp16 mode (attentionh.hip): qkv / ctx in halves, head_dim 32/64/128/256, any S; qkv_rows = readable rows of qkv
 bool attentionh_supported(int S, int H, int d);
 hipError_t launch_attentionh(const _Float16* qkv, _Float16* ctx, int B, int S, int H, int d, long qkv_rows, hipStream_t s);
 

@@ -175,10 +175,15 @@ LOOPS = ["p20", "p20_cfg", "ddim10", "ddim10_cfg", "ddim10_eta05", "p20_const_no
 def test_loops_tiny_vs_reference_golden(arch, name, fused):
     """Whole sampling loops with the reference's recorded noise tape: fused C++ loop
     (gdx_sample_loop) and the step-wise callable protocol (model(x, t, y) + gdx_sampler_update)."""
+    _run_loop_case(arch, name, fused, "fp32", LOOP_TOL)
+
+
+def _run_loop_case(arch, name, fused, compute_dtype, tol):
     from gesturediffusion_amd.model.cfg_sampler import ClassifierFreeSampleModel
     g = load_golden(f"loops_{arch}_tiny.npz")
     d = dev()
     m = build_model(arch, TINY, weights_from(g))
+    m.compute_dtype = compute_dtype
     tape = torch.from_numpy(g["tape"]).to(d)
     y = {"seed": torch.from_numpy(g["seed"]).to(d), "mfcc": torch.from_numpy(g["mfcc"]).to(d)}
     model = m
@@ -221,7 +226,7 @@ def test_loops_tiny_vs_reference_golden(arch, name, fused):
         finally:
             torch.randn_like = orig
     r = torch.stack(list(r)) if isinstance(r, list) else r
-    assert rel_err(r.cpu(), g[name]) < LOOP_TOL, name
+    assert rel_err(r.cpu(), g[name]) < tol, name
 
 
 @pytest.mark.parametrize("arch", ["mdm", "mdm_old"])
@@ -377,3 +382,88 @@ def test_generate_cli_synthetic(tmp_path, extra):
     frames = int(extra[extra.index("--num_frames") + 1])
     assert res["motion"].shape == (3, 37, 1, 2 * frames) and np.isfinite(res["motion"]).all()
     assert np.abs(res["motion"]).max() > 0
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# fp16 compute mode (BASELINE config 5's reduced-precision variant): fp16 MFMA operands, fp32 accumulate.
+# Tolerance from SURVEY.md section 8d: <= 2e-2 of max|ref| against the reference's fp32 outputs (measured ~6e-4).
+F16_TOL = 2e-2
+
+
+@pytest.mark.parametrize("M,N,K,gelu", [(1000, 1024, 512, 0), (333, 320, 576, 0), (257, 1536, 512, 1), (64, 64, 64, 1),
+                                        (4100, 512, 1024, 0)])
+def test_fp16_gemm_vs_torch(M, N, K, gelu):
+    """csrc/gemmh.hip through the C ABI: exact products of the fp16-rounded operands, fp32 accumulate -> the fp32
+    output matches an fp64 reference on the same rounded operands to fp32 round-off; the fp16 output to fp16 round-off."""
+    import ctypes as C
+    from gesturediffusion_amd import _lib
+    lib = _lib.load()
+    d = dev()
+    g = torch.Generator(device=d).manual_seed(M + N)
+    A = torch.randn(M, K, device=d, generator=g)
+    W = torch.randn(N, K, device=d, generator=g) / K ** 0.5
+    b = torch.randn(N, device=d, generator=g)
+    C32 = torch.full((M, N), float("nan"), device=d)
+    C16 = torch.full((M, N), float("nan"), device=d)
+    vp = lambda t: C.c_void_p(t.data_ptr())   # noqa: E731
+    s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    _lib.check(lib.gdx_linear_f16(vp(A), vp(W), vp(b), vp(C32), vp(C16), M, N, K, gelu, s), lib)
+    ref = A.half().double() @ W.half().double().t() + b.double()
+    if gelu:
+        ref = torch.nn.functional.gelu(ref)
+    assert rel_err(C32.cpu().double(), ref.cpu()) < (3e-5 if gelu else 2e-6)    # GELU: polynomial erf, |err| <= 1.1e-5 |x|
+    assert rel_err(C16.cpu().double(), ref.cpu()) < 1e-3
+
+
+@pytest.mark.parametrize("B,S,H,dm", [(2, 197, 4, 512), (1, 521, 4, 1024), (3, 250, 2, 128), (2, 31, 8, 512), (2, 1, 4, 512),
+                                      (1, 300, 4, 256), (2, 77, 4, 128)])
+def test_fp16_attention_vs_torch(B, S, H, dm):
+    """csrc/attentionh.hip (head_dim 32/64/128/256, ragged sequence lengths, single token) against fp64 softmax
+    attention on the fp16-rounded q/k/v."""
+    import ctypes as C
+    from gesturediffusion_amd import _lib
+    lib = _lib.load()
+    d = dev()
+    hd = dm // H
+    g = torch.Generator(device=d).manual_seed(S)
+    qkv = torch.randn(B * S, 3 * dm, device=d, generator=g)
+    qkv[:, :dm] *= 2.0
+    ctx = torch.full((B * S, dm), float("nan"), device=d)
+    s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    _lib.check(lib.gdx_attention_f16(C.c_void_p(qkv.data_ptr()), C.c_void_p(ctx.data_ptr()), B, S, H, dm, s), lib)
+    r = qkv.half().double().view(B, S, 3, H, hd)
+    q, k, v = (r[:, :, i].permute(0, 2, 1, 3) for i in range(3))
+    p = torch.softmax(q @ k.transpose(-1, -2) / hd ** 0.5, dim=-1)
+    ref = (p @ v).permute(0, 2, 1, 3).reshape(B * S, dm)
+    assert rel_err(ctx.cpu().double(), ref.cpu()) < 2e-3
+
+
+@pytest.mark.parametrize("name,arch,J,dm", [("c1_v2", "mdm", 150, 512), ("c2_v1", "mdm_old", 263, 512),
+                                            ("c5_v2", "mdm", 498, 1024)])
+def test_fp16_mode_real_shapes_vs_reference_golden(name, arch, J, dm):
+    """fp16 mode at BASELINE shapes (incl. config 5: d=1024, T=520) against the reference's own fp32 outputs."""
+    from gesturediffusion_amd.utils.init import init_state_dict, synthetic_inputs
+    g = load_golden("real_shapes.npz")
+    B, T = int(g[name + ".meta"][0]), int(g[name + ".meta"][1])
+    cfg = _real_cfg(arch, J, dm)
+    m = build_model(arch, cfg, init_state_dict(cfg, seed=0))
+    m.compute_dtype = "fp16"
+    x, seedp, mfcc = synthetic_inputs(cfg, B, T, seed=10)
+    d = dev()
+    t = torch.from_numpy(g[name + ".t"]).to(d)
+    y = {"seed": seedp.to(d), "mfcc": mfcc.to(d)}
+    assert rel_err(m(x.to(d), t, y).cpu(), g[name + ".out"]) < F16_TOL
+    assert rel_err(m(x.to(d), t, dict(y, uncond=True)).cpu(), g[name + ".out_uncond"]) < F16_TOL
+    if name == "c1_v2":
+        gen = torch.Generator().manual_seed(77)
+        tape = torch.randn(11, B, J, 1, T, generator=gen).to(d)
+        r = _diffusion("ddim10").ddim_sample_loop(m, (B, J, 1, T), noise_tape=tape, clip_denoised=False,
+                                                   model_kwargs={"y": y})
+        assert rel_err(r.cpu(), g["c1_v2.ddim10"]) < F16_TOL
+
+
+@pytest.mark.parametrize("arch", ["mdm", "mdm_old"])
+@pytest.mark.parametrize("name", ["p20", "p20_cfg", "ddim10_cfg", "p20_cfg_inpaint"])
+def test_fp16_mode_loops_vs_reference_golden(arch, name):
+    """fp16 mode through whole sampling loops (fused C++ loop) against the reference's fp32 loops, same noise tape."""
+    _run_loop_case(arch, name, True, "fp16", F16_TOL)
