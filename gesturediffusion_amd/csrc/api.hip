@@ -69,7 +69,7 @@ struct gdx_model {
     int d, J, ff, L, H;
     bool f16 = false;                 // cfg.compute_dtype == GDX_DTYPE_F16: fp16 MFMA operands, fp32 accumulate
     _Float16 *xt16 = nullptr, *xa16 = nullptr, *xb16 = nullptr, *qkv16 = nullptr, *ctx16 = nullptr, *ffb16 = nullptr,
-             *emb16 = nullptr, *xc16 = nullptr;
+             *emb16 = nullptr, *xc16 = nullptr, *tmp16 = nullptr;
     std::set<std::string> have;
     std::vector<std::string> required;
     std::vector<void*> allocs;        // weight allocations
@@ -350,15 +350,19 @@ extern "C" int gdx_prepare(gdx_handle_t h, int32_t batch, int32_t frames) {
         if (hipMemset(*p, 0, n * sizeof(float)) != hipSuccess) return fail("gdx_prepare: hipMemset failed");
         return 0;
     };
-    if (A(&h->xa, N * d) || A(&h->xb, N * d) || A(&h->qkv, N * 3 * d) || A(&h->ctx, N * d) || A(&h->tmp, N * d) ||
-        A(&h->ffb, N * h->ff) || A(&h->addend, N * d) || A(&h->seed_cat, B2 * d) || A(&h->temb_in, B2 * d) ||
+    if (A(&h->xa, N * d) || A(&h->addend, N * d) || A(&h->seed_cat, B2 * d) || A(&h->temb_in, B2 * d) ||
         A(&h->temb_h, B2 * d) || A(&h->temb, B2 * d) || A(&h->coa, B2 * d) || A(&h->c2, (B2 + 1) * d) ||
         A(&h->x0, B2 * h->J * (size_t)frames))
         return -1;
+    // fp32 activation buffers of the fp32 mode (the fp16 mode keeps its stream in the *16 buffers below)
+    if (!h->f16 && (A(&h->xb, N * d) || A(&h->qkv, N * 3 * d) || A(&h->ctx, N * d) || A(&h->tmp, N * d) || A(&h->ffb, N * h->ff)))
+        return -1;
     h->ldo = round_up(h->J, 64);
     const size_t NT = B2 * frames + 128;
-    if (A(&h->xt, NT * round_up(h->J, 32)) || A(&h->xc, NT * d) || A(&h->x0t, NT * h->ldo)) return -1;
-    if (h->cfg.arch == GDX_ARCH_MDM && (A(&h->emb_pose, (B2 * frames + 128) * d) || A(&h->xseq, (B2 * frames + 128) * d))) return -1;
+    if (A(&h->x0t, NT * h->ldo)) return -1;
+    if (!h->f16 && (A(&h->xt, NT * round_up(h->J, 32)) || A(&h->xc, NT * d))) return -1;
+    if (h->cfg.arch == GDX_ARCH_MDM && A(&h->xseq, NT * d)) return -1;
+    if (h->cfg.arch == GDX_ARCH_MDM && !h->f16 && A(&h->emb_pose, NT * d)) return -1;
     if (h->f16) {
         auto H16 = [&](_Float16** p, size_t n) {
             if (dev_alloc(h->ws_allocs, (void**)p, n * 2)) return -1;
@@ -366,7 +370,7 @@ extern "C" int gdx_prepare(gdx_handle_t h, int32_t batch, int32_t frames) {
             return 0;
         };
         if (H16(&h->xt16, NT * round_up(h->J, 64)) || H16(&h->xa16, N * d) || H16(&h->xb16, N * d) ||
-            H16(&h->qkv16, N * 3 * d) || H16(&h->ctx16, N * d) || H16(&h->ffb16, N * h->ff) || H16(&h->xc16, NT * d))
+            H16(&h->qkv16, N * 3 * d) || H16(&h->ctx16, N * d) || H16(&h->tmp16, N * d) || H16(&h->ffb16, N * h->ff) || H16(&h->xc16, NT * d))
             return -1;
         if (h->cfg.arch == GDX_ARCH_MDM && H16(&h->emb16, NT * d)) return -1;
     }
@@ -530,9 +534,10 @@ static int gemm_f16(const _Float16* A, int lda, const Packed& P, const float* bi
     return 0;
 }
 
-// The per-step kernel sequence of the fp16 mode: every GEMM operand (activations and weights) is fp16, every
-// accumulation, bias / residual add, LayerNorm and softmax is fp32, the residual stream is kept in fp32 (xa / xb)
-// next to the fp16 copy the next GEMM reads (xa16 / xb16).
+// The per-step kernel sequence of the fp16 mode: the whole activation stream (GEMM operands, GEMM outputs, the
+// residual stream xa16 / xb16, LayerNorm inputs and outputs, q/k/v, probabilities, context) is fp16; every
+// accumulation (MFMA, bias / residual terms in the GEMM epilogues, LayerNorm statistics, softmax) is fp32.  The two
+// boundary tensors stay fp32: the pose tensor read by the input transpose and the x0 prediction (fp32 output GEMM).
 static int forward_core_f16(gdx_model* h, const float* x, const float* temb, int tstride, int mode, float* x0_out,
                             hipStream_t s) {
     const int B = h->B, T = h->T, S = h->S, d = h->d, J = h->J;
@@ -540,10 +545,11 @@ static int forward_core_f16(gdx_model* h, const float* x, const float* temb, int
     const float* seed_emb = mode == GDX_UNCOND ? h->seed_cat + (size_t)B * d : h->seed_cat;
     const int N = Beff * S;
     const int Jp = h->in_x.kpad16;
+    float* const tap32 = h->keep_taps ? h->xa : nullptr;              // fp32 copies only for the parity taps
     HIPCHK(launch_transpose_in_f16(x, h->xt16, Beff, B, J, T, Jp, s));
     if (h->cfg.arch == GDX_ARCH_MDM_OLD) {
         HIPCHK(launch_token0(temb, tstride, seed_emb, h->pe, h->xa, h->xa16, nullptr, Beff, B, S, d, s));
-        if (gemm_f16(h->xt16, Jp, h->in_x, nullptr, h->addend, d, nullptr, 0, h->xa, d, h->xa16, d, Beff * T, d, T, 1, 0, s))
+        if (gemm_f16(h->xt16, Jp, h->in_x, nullptr, h->addend, d, nullptr, 0, tap32, d, h->xa16, d, Beff * T, d, T, 1, 0, s))
             return -1;
     } else {
         HIPCHK(launch_token0(temb, tstride, seed_emb, nullptr, h->xa, h->xa16, h->coa, Beff, B, S, d, s));
@@ -562,8 +568,8 @@ static int forward_core_f16(gdx_model* h, const float* x, const float* temb, int
         if (gemm_f16(h->xa16, d, ly.qkv, ly.qkv.bias, nullptr, 0, nullptr, 0, nullptr, 0, h->qkv16, 3 * d, N, 3 * d, T, 0, 0, s))
             return -1;
         HIPCHK(launch_attentionh(h->qkv16, h->ctx16, Beff, S, h->H, d, h->rows_alloc, s));
-        if (gemm_f16(h->ctx16, d, ly.out, ly.out.bias, nullptr, 0, nullptr, 0, h->tmp, d, nullptr, 0, N, d, T, 0, 0, s)) return -1;
-        HIPCHK(launch_layernorm(h->tmp, h->xa, ly.g1, ly.b1, h->xb, h->xb16, N, d, 0, s));
+        if (gemm_f16(h->ctx16, d, ly.out, ly.out.bias, nullptr, 0, nullptr, 0, nullptr, 0, h->tmp16, d, N, d, T, 0, 0, s)) return -1;
+        HIPCHK(launch_layernorm_f16(h->tmp16, h->xa16, ly.g1, ly.b1, h->xb16, nullptr, N, d, 0, s));
         const bool stamp = h->prof && h->prof_used + 2 <= h->prof_ev.size();
         if (stamp) HIPCHK(hipEventRecord(h->prof_ev[h->prof_used], s));
         if (gemm_f16(h->xb16, d, ly.ff1, ly.ff1.bias, nullptr, 0, nullptr, 0, nullptr, 0, h->ffb16, h->ff, N, h->ff, T, 0, 1, s))
@@ -572,11 +578,11 @@ static int forward_core_f16(gdx_model* h, const float* x, const float* temb, int
             HIPCHK(hipEventRecord(h->prof_ev[h->prof_used + 1], s));
             h->prof_used += 2;
         }
-        if (gemm_f16(h->ffb16, h->ff, ly.ff2, ly.ff2.bias, nullptr, 0, nullptr, 0, h->tmp, d, nullptr, 0, N, d, T, 0, 0, s))
+        if (gemm_f16(h->ffb16, h->ff, ly.ff2, ly.ff2.bias, nullptr, 0, nullptr, 0, nullptr, 0, h->tmp16, d, N, d, T, 0, 0, s))
             return -1;
         const bool last = l + 1 == h->L;
-        if (!last || h->keep_taps) HIPCHK(launch_layernorm(h->tmp, h->xb, ly.g2, ly.b2, h->xa, h->xa16, N, d, 0, s));
-        if (last) HIPCHK(launch_layernorm(h->tmp, h->xb, ly.g2, ly.b2, nullptr, h->xc16, N, d, S, s));
+        if (!last || h->keep_taps) HIPCHK(launch_layernorm_f16(h->tmp16, h->xb16, ly.g2, ly.b2, h->xa16, tap32, N, d, 0, s));
+        if (last) HIPCHK(launch_layernorm_f16(h->tmp16, h->xb16, ly.g2, ly.b2, h->xc16, nullptr, N, d, S, s));
         if (h->keep_taps)
             HIPCHK(hipMemcpyAsync(h->taps[l + 1], h->xa, sizeof(float) * (size_t)N * d, hipMemcpyDeviceToDevice, s));
     }
@@ -716,6 +722,7 @@ extern "C" int gdx_forward_flops(gdx_handle_t h, int32_t mode, double* flops) {
 extern "C" int gdx_bench_ffn_gemm(gdx_handle_t h, int32_t iters, float* avg_us, void* stream) {
     if (!h || !avg_us) return fail("gdx_bench_ffn_gemm: null argument");
     if (!h->B) return fail("gdx_bench_ffn_gemm: call gdx_prepare first");
+    if (h->f16) return fail("gdx_bench_ffn_gemm: fp32 mode only (use gdx_bench_gemm_f16)");
     if (gdx_weights_ready(h)) return -1;
     hipStream_t s = (hipStream_t)stream;
     const int N = h->B * h->S, d = h->d;

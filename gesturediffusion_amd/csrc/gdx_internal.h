@@ -74,6 +74,9 @@ hipError_t launch_attentionh(const _Float16* qkv, _Float16* ctx, int B, int S, i
 // out (fp32) and out16 (fp16 copy for the reduced-precision GEMMs) are each optional
 hipError_t launch_layernorm(const float* x, const float* res, const float* gamma, const float* beta, float* out,
                             _Float16* out16, int rows, int d, int compact_S, hipStream_t s);
+// fp16-mode LayerNorm: out16 = LN(x + res) with fp16 x / res (res may be nullptr), fp32 statistics; out32 optional
+hipError_t launch_layernorm_f16(const _Float16* x, const _Float16* res, const float* gamma, const float* beta,
+                                _Float16* out16, float* out32, int rows, int d, int compact_S, hipStream_t s);
 hipError_t launch_transpose_in(const float* x, float* xt, int B, int Bsrc, int J, int T, int ldx, hipStream_t s);
 hipError_t launch_transpose_in_f16(const float* x, _Float16* xt, int B, int Bsrc, int J, int T, int ldx, hipStream_t s);
 hipError_t launch_transpose_out(const float* yt, float* y, int B, int J, int T, int ldy, hipStream_t s);

@@ -116,6 +116,116 @@ hipError_t launch_layernorm(const float* x, const float* res, const float* gamma
     return hipGetLastError();
 }
 
+// fp16-mode LayerNorm: x and the residual are fp16 (the whole activation stream of the fp16 mode is fp16), statistics
+// and the affine transform are fp32, output fp16 (+ optional fp32 copy for the parity taps).  One wave per row,
+// 8 halves (16 B) per lane per load.  HBM-bound: 3 * rows * d * 2 bytes.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+template <int NV>   // 16-byte loads per lane: d = 512 * NV
+__global__ __launch_bounds__(256) void layernorm_h_vec_kernel(const _Float16* __restrict__ x, const _Float16* __restrict__ res,
+                                                               const float* __restrict__ g, const float* __restrict__ bta,
+                                                               _Float16* __restrict__ out16, float* __restrict__ out32,
+                                                               int rows, int d, int compact_S) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    long orow = row;
+    if (compact_S > 0) {
+        const int b = row / compact_S;
+        if (row - b * compact_S == 0) return;
+        orow = row - b - 1;
+    }
+    const f16x8* xp = reinterpret_cast<const f16x8*>(x + (long)row * d);
+    const f16x8* rp = reinterpret_cast<const f16x8*>(res + (long)row * d);
+    float v[NV][8];
+    float s = 0.0f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const f16x8 a = xp[lane + 64 * i];
+        f16x8 r = f16x8{0, 0, 0, 0, 0, 0, 0, 0};
+        if (res) r = rp[lane + 64 * i];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            v[i][e] = (float)a[e] + (float)r[e];
+            s += v[i][e];
+        }
+    }
+    const float mean = wave_sum(s) / (float)d;
+    float q = 0.0f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float c = v[i][e] - mean;
+            q += c * c;
+        }
+    const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)d + 1e-5f);
+    const f32x4* gp = reinterpret_cast<const f32x4*>(g);
+    const f32x4* bp = reinterpret_cast<const f32x4*>(bta);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c4 = 2 * (lane + 64 * i);
+        const f32x4 g0 = gp[c4], g1 = gp[c4 + 1], b0 = bp[c4], b1 = bp[c4 + 1];
+        float r[8];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            r[e] = (v[i][e] - mean) * rstd * g0[e] + b0[e];
+            r[4 + e] = (v[i][4 + e] - mean) * rstd * g1[e] + b1[e];
+        }
+        reinterpret_cast<f16x8*>(out16 + orow * d)[lane + 64 * i] =
+            f16x8{(_Float16)r[0], (_Float16)r[1], (_Float16)r[2], (_Float16)r[3], (_Float16)r[4], (_Float16)r[5], (_Float16)r[6], (_Float16)r[7]};
+        if (out32) {
+            f32x4* op = reinterpret_cast<f32x4*>(out32 + orow * d);
+            op[c4] = f32x4{r[0], r[1], r[2], r[3]};
+            op[c4 + 1] = f32x4{r[4], r[5], r[6], r[7]};
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void layernorm_h_gen_kernel(const _Float16* __restrict__ x, const _Float16* __restrict__ res,
+                                                               const float* __restrict__ g, const float* __restrict__ bta,
+                                                               _Float16* __restrict__ out16, float* __restrict__ out32,
+                                                               int rows, int d, int compact_S) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    long orow = row;
+    if (compact_S > 0) {
+        const int b = row / compact_S;
+        if (row - b * compact_S == 0) return;
+        orow = row - b - 1;
+    }
+    const _Float16* xp = x + (long)row * d;
+    const _Float16* rp = res + (long)row * d;
+    auto at = [&](int e) { return res ? (float)xp[e] + (float)rp[e] : (float)xp[e]; };
+    float s = 0.0f;
+    for (int e = lane; e < d; e += 64) s += at(e);
+    const float mean = wave_sum(s) / (float)d;
+    float q = 0.0f;
+    for (int e = lane; e < d; e += 64) {
+        const float c = at(e) - mean;
+        q += c * c;
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)d + 1e-5f);
+    for (int e = lane; e < d; e += 64) {
+        const float r = (at(e) - mean) * rstd * g[e] + bta[e];
+        out16[orow * d + e] = (_Float16)r;
+        if (out32) out32[orow * d + e] = r;
+    }
+}
+
+hipError_t launch_layernorm_f16(const _Float16* x, const _Float16* res, const float* gamma, const float* beta,
+                                _Float16* out16, float* out32, int rows, int d, int compact_S, hipStream_t s) {
+    const dim3 grid((rows + 3) / 4), block(256);
+    if (d == 512)
+        hipLaunchKernelGGL(layernorm_h_vec_kernel<1>, grid, block, 0, s, x, res, gamma, beta, out16, out32, rows, d, compact_S);
+    else if (d == 1024)
+        hipLaunchKernelGGL(layernorm_h_vec_kernel<2>, grid, block, 0, s, x, res, gamma, beta, out16, out32, rows, d, compact_S);
+    else
+        hipLaunchKernelGGL(layernorm_h_gen_kernel, grid, block, 0, s, x, res, gamma, beta, out16, out32, rows, d, compact_S);
+    return hipGetLastError();
+}
+
 // ---------------------------------------------------------------------------------------------
 // Pose-tensor <-> token-major transposes around the boundary GEMMs (model/mdm.py:350-356 InputProcess permute,
 // :372-380 OutputProcess permute).  32x32 tiles through LDS, coalesced on both sides.  ~26 MB each way at
