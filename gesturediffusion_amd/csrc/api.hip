@@ -890,6 +890,22 @@ extern "C" int gdx_bench_gemm_f16(int32_t M, int32_t N, int32_t K, int32_t gelu,
     }
     if (e0) (void)hipEventDestroy(e0);
     if (e1) (void)hipEventDestroy(e1);
+    if (!rc && getenv("GDX_GEMM_DEBUG")) {      // one extra launch with loader-wave stamps (diagnostic path only)
+        unsigned long long* dd = nullptr;
+        if (!dev_alloc(pool, (void**)&dd, 512)) {
+            (void)hipMemsetAsync(dd, 0, 512, s);
+            g2_dbg_buf = dd;
+            (void)launch_gemmh(p, s);
+            g2_dbg_buf = nullptr;
+            unsigned long long hh[8] = {0};
+            (void)hipMemcpyAsync(hh, dd, 64, hipMemcpyDeviceToHost, s);
+            (void)hipStreamSynchronize(s);
+            if (hh[3])
+                fprintf(stderr, "[gemmh stamps] loader wave, block 0: %llu steps; per step: issue %.0f, vmcnt wait %.0f, barrier wait %.0f, total %.0f cycles; loop %.1f us -> s_memtime at %.2f GHz\n",
+                        hh[3], (double)hh[0] / hh[3], (double)hh[1] / hh[3], (double)hh[2] / hh[3], (double)hh[4] / hh[3],
+                        hh[5] / 100.0, hh[5] ? (double)hh[4] / (hh[5] * 10.0) : 0.0);
+        }
+    }
     (void)hipStreamSynchronize(s);
     free_pool(pool);
     return rc;

@@ -26,8 +26,11 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <type_traits>
 
 namespace gdx {
+
+extern unsigned long long* g2_dbg_buf;   // gemm2.hip: set by the bench helpers when GDX_GEMM_DEBUG is set
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
@@ -59,8 +62,85 @@ __device__ __forceinline__ f32x2 gelu2(f32x2 x) {
     return h + h * (z * pl);
 }
 
+// Epilogue of one wave: its MB x NBW accumulator blocks (swapped MFMA: lane & 15 = row inside a 16-row block, registers
+// = columns q*4*NBW + j*4 + e) -> bias / R / V / GELU -> fp32 and / or fp16 stores.  (m0, nw0) = first row / column of
+// the wave's sub-tile.  Clears the accumulators.
+template <int MB, int NBW>
+__device__ __forceinline__ void wave_epilogue(const GemmHParams& p, f32x4 (&acc)[MB][NBW], const float* bias_lds, int m0,
+                                              int nw0, int l15, int lq) {
+    const int nb = nw0 + lq * (4 * NBW);
+    f32x4 bv[NBW];
+#pragma unroll
+    for (int j = 0; j < NBW; ++j) bv[j] = *reinterpret_cast<const f32x4*>(&bias_lds[nb + j * 4]);
+#pragma unroll
+    for (int i = 0; i < MB; ++i) {
+        const int m = m0 + i * 16 + l15;
+        f32x4 v[NBW];
+#pragma unroll
+        for (int j = 0; j < NBW; ++j) {
+            v[j] = acc[i][j] + bv[j];
+            acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        if (m < p.M) {
+            long ro = m;
+            int bs = 0;
+            if (p.rowmap || p.V) {
+                bs = m / p.T;
+                if (p.rowmap) ro = (long)m + bs + 1;
+            }
+            if (p.R) {
+#pragma unroll
+                for (int j = 0; j < NBW; ++j) v[j] += *reinterpret_cast<const f32x4*>(&p.R[ro * p.ldr + nb + j * 4]);
+            }
+            if (p.V) {
+#pragma unroll
+                for (int j = 0; j < NBW; ++j) v[j] += *reinterpret_cast<const f32x4*>(&p.V[(long)bs * p.ldv + nb + j * 4]);
+            }
+            if (p.gelu) {
+#pragma unroll
+                for (int j = 0; j < NBW; ++j) {
+                    const f32x2 lo = gelu2(f32x2{v[j][0], v[j][1]}), hi = gelu2(f32x2{v[j][2], v[j][3]});
+                    v[j] = f32x4{lo.x, lo.y, hi.x, hi.y};
+                }
+            }
+            if (p.C32) {
+#pragma unroll
+                for (int j = 0; j < NBW; ++j) *reinterpret_cast<f32x4*>(&p.C32[ro * p.ldc32 + nb + j * 4]) = v[j];
+            }
+            if (p.C16) {
+                _Float16* cp = p.C16 + ro * p.ldc16 + nb;
+                if constexpr (NBW == 1) {
+                    *reinterpret_cast<f16x4*>(cp) =
+                        f16x4{(_Float16)v[0][0], (_Float16)v[0][1], (_Float16)v[0][2], (_Float16)v[0][3]};
+                } else {
+#pragma unroll
+                    for (int j = 0; j < NBW; j += 2)
+                        *reinterpret_cast<f16x8*>(cp + j * 4) =
+                            f16x8{(_Float16)v[j][0],     (_Float16)v[j][1],     (_Float16)v[j][2],     (_Float16)v[j][3],
+                                  (_Float16)v[j + 1][0], (_Float16)v[j + 1][1], (_Float16)v[j + 1][2], (_Float16)v[j + 1][3]};
+                }
+            }
+        }
+    }
+}
+
+// scheduling recipe for one K step: one ds_read after every PER MFMAs over the first ~2/3 of the NMM MFMAs, the
+// rest of the MFMAs behind the last read (so its latency is covered before the step's lgkmcnt(0) + barrier)
+template <int R, int NRD, int NMM>
+__device__ __forceinline__ void sched_interleave() {
+    constexpr int PER = (2 * NMM / 3) / NRD > 0 ? (2 * NMM / 3) / NRD : 1;
+    if constexpr (R < NRD) {
+        __builtin_amdgcn_sched_group_barrier(0x008, PER, 0);      // MFMA
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);        // DS read
+        sched_interleave<R + 1, NRD, NMM>();
+    } else if constexpr (NMM > PER * NRD) {
+        __builtin_amdgcn_sched_group_barrier(0x008, NMM - PER * NRD, 0);
+    }
+}
+
 template <int MB, int NBW, int NST>
-__global__ __launch_bounds__(512, 1) void gemmh_kernel(const GemmHParams p, const int ntn, const int ntiles) {
+__global__ __launch_bounds__(512, 1) void gemmh_kernel(const GemmHParams p, const int ntn, const int ntiles,
+                                                       unsigned long long* dbg) {
 #if defined(__HIP_DEVICE_COMPILE__)   // the host pass only needs the launch stub (buffer-resource builtins are device-only)
     constexpr int BM = MB * 16, WN = NBW * 16, BN = WN * 4;
     constexpr int A_BYTES = BM * 64, W_BYTES = BN * 64, STAGE_BYTES = A_BYTES + W_BYTES;
@@ -137,6 +217,28 @@ __global__ __launch_bounds__(512, 1) void gemmh_kernel(const GemmHParams p, cons
         wait_vm_h<VM_STEP>();
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         int wst = NST - 1;
+        if (dbg) {                                                // diagnostic build path (GDX_GEMM_DEBUG): where a loader spends its cycles
+            unsigned long long t_issue = 0, t_wait = 0, t_bar = 0;
+            const unsigned long long t_begin = __builtin_amdgcn_s_memtime(), r_begin = __builtin_amdgcn_s_memrealtime();
+            for (int g = 0; g < total; ++g) {
+                const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+                issue(wst);
+                wst = wst == NST - 1 ? 0 : wst + 1;
+                const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+                wait_vm_h<VM_STEP>();
+                const unsigned long long t2 = __builtin_amdgcn_s_memtime();
+                asm volatile("s_barrier" ::: "memory");
+                const unsigned long long t3 = __builtin_amdgcn_s_memtime();
+                t_issue += t1 - t0; t_wait += t2 - t1; t_bar += t3 - t2;
+            }
+            if (blockIdx.x == 0 && tid == 256) {
+                dbg[0] = t_issue; dbg[1] = t_wait; dbg[2] = t_bar; dbg[3] = (unsigned long long)total;
+                dbg[4] = __builtin_amdgcn_s_memtime() - t_begin;
+                dbg[5] = __builtin_amdgcn_s_memrealtime() - r_begin;   // 100 MHz
+            }
+            wait_vm_h<0>();
+            return;
+        }
         for (int g = 0; g < total; ++g) {
             issue(wst);                                           // slab g+NST-1 -> the stage freed by the last barrier
             wst = wst == NST - 1 ? 0 : wst + 1;
@@ -173,88 +275,244 @@ __global__ __launch_bounds__(512, 1) void gemmh_kernel(const GemmHParams p, cons
     };
     int ks = 0, stage = 0, tile_i = 0;
     auto epilogue = [&]() {
-        // accumulator: lane & 15 = output row inside the 16-row block, registers = columns q*4*NBW + j*4 + e
         const int tile = lid + tile_i * G;
         ++tile_i;
-        const int m0 = (tile / ntn) * BM, n0 = (tile % ntn) * BN;
-        const int nb = n0 + wave * WN + lq * (4 * NBW);
-        f32x4 bv[NBW];
-#pragma unroll
-        for (int j = 0; j < NBW; ++j) bv[j] = *reinterpret_cast<const f32x4*>(&bias_lds[nb + j * 4]);
-#pragma unroll
-        for (int i = 0; i < MB; ++i) {
-            const int m = m0 + i * 16 + l15;
-            f32x4 v[NBW];
-#pragma unroll
-            for (int j = 0; j < NBW; ++j) {
-                v[j] = acc[i][j] + bv[j];
-                acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-            }
-            if (m < p.M) {
-                long ro = m;
-                int bs = 0;
-                if (p.rowmap || p.V) {
-                    bs = m / p.T;
-                    if (p.rowmap) ro = (long)m + bs + 1;
-                }
-                if (p.R) {
-#pragma unroll
-                    for (int j = 0; j < NBW; ++j) v[j] += *reinterpret_cast<const f32x4*>(&p.R[ro * p.ldr + nb + j * 4]);
-                }
-                if (p.V) {
-#pragma unroll
-                    for (int j = 0; j < NBW; ++j) v[j] += *reinterpret_cast<const f32x4*>(&p.V[(long)bs * p.ldv + nb + j * 4]);
-                }
-                if (p.gelu) {
-#pragma unroll
-                    for (int j = 0; j < NBW; ++j) {
-                        const f32x2 lo = gelu2(f32x2{v[j][0], v[j][1]}), hi = gelu2(f32x2{v[j][2], v[j][3]});
-                        v[j] = f32x4{lo.x, lo.y, hi.x, hi.y};
-                    }
-                }
-                if (p.C32) {
-#pragma unroll
-                    for (int j = 0; j < NBW; ++j) *reinterpret_cast<f32x4*>(&p.C32[ro * p.ldc32 + nb + j * 4]) = v[j];
-                }
-                if (p.C16) {
-                    _Float16* cp = p.C16 + ro * p.ldc16 + nb;
-                    if constexpr (NBW == 1) {
-                        *reinterpret_cast<f16x4*>(cp) =
-                            f16x4{(_Float16)v[0][0], (_Float16)v[0][1], (_Float16)v[0][2], (_Float16)v[0][3]};
-                    } else {
-#pragma unroll
-                        for (int j = 0; j < NBW; j += 2)
-                            *reinterpret_cast<f16x8*>(cp + j * 4) =
-                                f16x8{(_Float16)v[j][0],     (_Float16)v[j][1],     (_Float16)v[j][2],     (_Float16)v[j][3],
-                                      (_Float16)v[j + 1][0], (_Float16)v[j + 1][1], (_Float16)v[j + 1][2], (_Float16)v[j + 1][3]};
-                    }
-                }
-            }
-        }
+        wave_epilogue<MB, NBW>(p, acc, bias_lds, (tile / ntn) * BM, (tile % ntn) * BN + wave * WN, l15, lq);
     };
 
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // slabs 0..2 landed (loaders waited)
+    // End of a K step.  The wait and the barrier are builtins (not inline asm) so that the compiler's waitcnt pass
+    // knows the fragment reads have completed and inserts no conservative waits in front of the next step's MFMAs,
+    // and sched_barrier pins the pair behind the step's MFMAs (as inline asm it was hoisted above them, leaving the
+    // LDS latency of the 12 fragment reads exposed in every step: 1050 cycles per step instead of ~550).
+    auto step_sync = [&]() {
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_waitcnt(0xc07f);                       // lgkmcnt(0)
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");                            // LDS contents change across the barrier (DMA)
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    // One K step: the MB + NBW fragment reads of the NEXT slab are spread between this slab's MB * NBW MFMAs
+    // (an MFMA holds the SIMD's vector issue for only half of its 16 cycles, so a ds_read in its shadow is free,
+    // while a block of 12 reads in front of the MFMAs idles the matrix pipe for ~100 cycles per step).
+    auto interleave = [&]() { sched_interleave<0, MB + NBW, MB * NBW>(); };
+    step_sync();                                                  // slabs 0 and 1 landed (loaders waited)
     rd(fa0, fw0, 0);
     for (int g = 0; g < total; g += 2) {
         // ---- even step: fragments of slab g are in (fa0, fw0)
         int nstage = stage == NST - 1 ? 0 : stage + 1;
         rd(fa1, fw1, nstage);                                     // slab g+1: landed before the last barrier
         mm(fa0, fw0);
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        interleave();
+        step_sync();
         stage = nstage;
         // ---- odd step (nk is even, so a tile always ends on an odd step)
         nstage = stage == NST - 1 ? 0 : stage + 1;
-        if (g + 2 < total) rd(fa0, fw0, nstage);
+        rd(fa0, fw0, nstage);                                     // past the last slab: reads a stale stage, never used
         mm(fa1, fw1);
+        interleave();
         ks += 2;
         if (ks == nk) {
             ks = 0;
             epilogue();
         }
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        step_sync();
         stage = nstage;
     }
 #endif
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// 256 x 256 tile, eight MFMA waves (2 x 4, each 128 x 64 like the kernel above), no dedicated loader waves.
+// Measured on the 128 x 256 kernel (ablation builds, M = 66 688, N = 3 072, K = 1 024): MFMA alone 385 us,
+// LDS-DMA alone 518 us -- the L2 -> LDS path sustains ~23 B/clk/CU, and a 128 x 256 tile needs 48 B/clk/CU to keep
+// the fp16 MFMA busy.  A 256 x 256 tile halves the staged bytes per MFMA (32 KiB per 64 MFMAs per SIMD); it needs
+// 8 x 128 accumulator registers, i.e. all eight waves computing, so every wave also issues its 1/8 of the DMA
+// (4 pieces per K step, spread between its MFMAs) and the two waves of a SIMD cover each other's issue stalls and
+// fragment reads.  Counted vmcnt waits stay valid with the epilogue's stores in flight (the count includes them,
+// so the wait can only be longer than needed, never shorter).
+template <int NST>
+__global__ __launch_bounds__(512, 1) void gemmh8_kernel(const GemmHParams p, const int ntn, const int ntiles,
+                                                        unsigned long long* dbg) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    constexpr int MB = 8, NBW = 4, WM = 128, WN = 64, BM = 256, BN = 256;
+    constexpr int A_BYTES = BM * 64, W_BYTES = BN * 64, STAGE_BYTES = A_BYTES + W_BYTES;      // 32 KiB
+    constexpr int A_P = A_BYTES / 1024, P = STAGE_BYTES / 1024, PW = P / 8;                    // 4 pieces per wave
+    constexpr int SHW = 4;
+    constexpr int VM_STEP = (NST - 3) * PW;
+    static_assert(NST >= 4 && P % 8 == 0, "ring depth");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* const bias_lds = reinterpret_cast<float*>(smem + NST * STAGE_BYTES);
+
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid) >> 6;
+    const int wr = wave >> 2, wc = wave & 3;
+    const int lane = tid & 63;
+    const int l15 = lane & 15, lq = lane >> 4;
+    const int G = gridDim.x;
+    int lid;
+    {
+        const int bid = blockIdx.x, q = G >> 3, r = G & 7, xcd = bid & 7, idx = bid >> 3;
+        lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int my_tiles = lid < ntiles ? (ntiles - lid + G - 1) / G : 0;
+    const int nk = p.K / 32;
+    const int total = my_tiles * nk;
+    if (total == 0) return;
+    for (int i = tid; i < p.N; i += 512) bias_lds[i] = p.bias ? p.bias[i] : 0.0f;
+
+    // ---- DMA set-up: this wave's 4 pieces of every slab (pieces wave, wave+8, ...: 2 of A, 2 of W)
+    const auto rsrcA = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(p.A), (short)0, p.a_bytes, 0x00020000);
+    const auto rsrcW = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(p.W), (short)0, p.w_bytes, 0x00020000);
+    int voff[PW];
+#pragma unroll
+    for (int i = 0; i < PW; ++i) {
+        const int piece = wave + 8 * i;
+        const bool isA = piece < A_P;
+        const int row = (isA ? piece : piece - A_P) * 16 + (lane >> 2);
+        const int g = (-(row >> (isA ? 2 : SHW))) & 3;
+        voff[i] = row * (isA ? p.lda : p.ldw) * 2 + (((lane & 3) ^ g) * 16);
+    }
+    // The DMA stream runs NST-1 slabs ahead of the MFMAs, so it crosses a tile boundary before they do.  Its tile
+    // base offsets advance by a select (no branch: the DMA issue must stay in the MFMA basic block to be interleaved);
+    // the base of the tile after next is computed once per tile, in the epilogue branch.
+    auto tile_base = [&](int ti, int& a_so, int& w_so) {
+        const int t = ti < my_tiles ? ti : my_tiles - 1;          // past the end: harmless re-reads
+        const int tile = lid + t * G;
+        a_so = (tile / ntn) * BM * p.lda * 2;
+        w_so = (tile % ntn) * BN * p.ldw * 2;
+    };
+    int ld_ks = 0, a_cur, w_cur, a_nxt, w_nxt;
+    tile_base(0, a_cur, w_cur);
+    tile_base(1, a_nxt, w_nxt);
+    auto issue = [&](int stage) {
+        const int a_so = a_cur + ld_ks * 64, w_so = w_cur + ld_ks * 64;
+        char* sb = smem + stage * STAGE_BYTES;
+#pragma unroll
+        for (int i = 0; i < PW; ++i) {
+            const int piece = wave + 8 * i;
+            if (piece < A_P)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcA, (lds_ptr_t)(sb + piece * 1024), 16, voff[i], a_so, 0, 0);
+            else
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcW, (lds_ptr_t)(sb + A_BYTES + (piece - A_P) * 1024), 16,
+                                                         voff[i], w_so, 0, 0);
+        }
+        ++ld_ks;
+        const bool wrap = ld_ks == nk;
+        ld_ks = wrap ? 0 : ld_ks;
+        a_cur = wrap ? a_nxt : a_cur;
+        w_cur = wrap ? w_nxt : w_cur;
+    };
+
+    f32x4 acc[MB][NBW];
+#pragma unroll
+    for (int i = 0; i < MB; ++i)
+#pragma unroll
+        for (int j = 0; j < NBW; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int gq = (-(l15 >> 2)) & 3;
+    const int a_off = (wr * WM + l15) * 64 + ((lq ^ gq) * 16);
+    const int w_off = A_BYTES + (wc * WN + (l15 >> 2) * (4 * NBW) + (l15 & 3)) * 64 + ((lq ^ gq) * 16);
+    f16x8 fa0[MB], fw0[NBW], fa1[MB], fw1[NBW];
+    auto rd = [&](f16x8 (&fa)[MB], f16x8 (&fw)[NBW], int stage) {
+        const char* S = smem + stage * STAGE_BYTES;
+#pragma unroll
+        for (int j = 0; j < NBW; ++j) fw[j] = *reinterpret_cast<const f16x8*>(S + w_off + j * 256);
+#pragma unroll
+        for (int i = 0; i < MB; ++i) fa[i] = *reinterpret_cast<const f16x8*>(S + a_off + i * 1024);
+    };
+    auto mm = [&](const f16x8 (&fa)[MB], const f16x8 (&fw)[NBW]) {
+#pragma unroll
+        for (int i = 0; i < MB; ++i)
+#pragma unroll
+            for (int j = 0; j < NBW; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fw[j], fa[i], acc[i][j], 0, 0, 0);
+    };
+    auto step_sync = [&]() {
+        __builtin_amdgcn_sched_barrier(0);
+        wait_vm_h<VM_STEP>();                                     // this wave's pieces of slab g+2 have landed
+        __builtin_amdgcn_s_waitcnt(0xc07f);                       // lgkmcnt(0)
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    // One K step: 4 DMA pieces, then 12 fragment reads, spread between the first 20 of the 32 MFMAs.  (Issuing the
+    // DMA among the LAST MFMAs in one of the two waves of a SIMD, to de-phase them, measured 17 % slower: the late
+    // pieces delay that wave's counted wait and with it the barrier.)
+    auto interleave = [&]() {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);    // MFMA
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);    // VMEM read (LDS-DMA piece)
+        }
+#pragma unroll
+        for (int r = 0; r < 12; ++r) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);    // DS read
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, 12, 0);
+    };
+
+#pragma unroll
+    for (int s = 0; s < NST - 1; ++s) issue(s);
+    wait_vm_h<VM_STEP>();                                         // slabs 0 and 1 (of this wave's pieces)
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    int ks = 0, stage = 0, tile_i = 0, wst = NST - 1;
+    rd(fa0, fw0, 0);
+    unsigned long long t0 = 0, r0 = 0;
+    if (dbg) { t0 = __builtin_amdgcn_s_memtime(); r0 = __builtin_amdgcn_s_memrealtime(); }
+    {
+        for (int g = 0; g < total; g += 2) {
+            int nstage = stage == NST - 1 ? 0 : stage + 1;
+            issue(wst);                                           // slab g+NST-1 -> the stage freed by the last barrier
+            wst = wst == NST - 1 ? 0 : wst + 1;
+            rd(fa1, fw1, nstage);
+            mm(fa0, fw0);
+            interleave();
+            step_sync();
+            stage = nstage;
+            nstage = stage == NST - 1 ? 0 : stage + 1;
+            issue(wst);
+            wst = wst == NST - 1 ? 0 : wst + 1;
+            rd(fa0, fw0, nstage);
+            mm(fa1, fw1);
+            interleave();
+            ks += 2;
+            if (ks == nk) {
+                ks = 0;
+                const int tile = lid + tile_i * G;
+                ++tile_i;
+                wave_epilogue<MB, NBW>(p, acc, bias_lds, (tile / ntn) * BM + wr * WM, (tile % ntn) * BN + wc * WN, l15, lq);
+                tile_base(tile_i + 1, a_nxt, w_nxt);              // the DMA stream is already inside tile tile_i
+            }
+            step_sync();
+            stage = nstage;
+        }
+    }
+    if (dbg && blockIdx.x == 0 && tid == 0) {                     // diagnostic stamps (GDX_GEMM_DEBUG)
+        dbg[4] = __builtin_amdgcn_s_memtime() - t0;
+        dbg[5] = __builtin_amdgcn_s_memrealtime() - r0;
+        dbg[3] = (unsigned long long)total;
+    }
+    wait_vm_h<0>();
+#endif
+}
+
+static hipError_t launch_cfg_h8(const GemmHParams& p, int num_cus, hipStream_t s) {
+    constexpr int NST = 4;
+    const size_t lds = (size_t)NST * 32768 + (size_t)p.N * 4;
+    static size_t attr_lds = 0;
+    if (lds > attr_lds) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemmh8_kernel<NST>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr_lds = lds;
+    }
+    const int ntm = (p.M + 255) / 256, ntn = p.N / 256;
+    const int ntiles = ntm * ntn;
+    const int grid = ntiles < num_cus ? ntiles : num_cus;
+    hipLaunchKernelGGL((gemmh8_kernel<NST>), dim3(grid), dim3(512), lds, s, p, ntn, ntiles, g2_dbg_buf);
+    return hipGetLastError();
 }
 
 template <int MB, int NBW, int NST>
@@ -276,7 +534,7 @@ static hipError_t launch_cfg_h(const GemmHParams& p, int num_cus, hipStream_t s)
     const int ntm = (p.M + BM - 1) / BM, ntn = p.N / BN;
     const int ntiles = ntm * ntn;
     const int grid = ntiles < num_cus ? ntiles : num_cus;
-    hipLaunchKernelGGL((gemmh_kernel<MB, NBW, NST>), dim3(grid), dim3(512), lds, s, p, ntn, ntiles);
+    hipLaunchKernelGGL((gemmh_kernel<MB, NBW, NST>), dim3(grid), dim3(512), lds, s, p, ntn, ntiles, g2_dbg_buf);
     return hipGetLastError();
 }
 
@@ -287,15 +545,28 @@ static bool gh_valid(int mb, int nbw, int nst, const GemmHParams& p) {
     return p.N % (nbw * 64) == 0 && (size_t)nst * (mb * 16 + nbw * 64) * 64 + (size_t)p.N * 4 <= 160 * 1024;
 }
 
-// Estimated cycles: rounds * (K steps * max(MFMA, staging) + epilogue)
+// Estimated microseconds: rounds * (K steps * measured step time + epilogue).  Step times measured on MI355X at
+// M = 66 688, K = 1 024 (tools/gemmh_sweep.sh): the kernels are bound by the L2 -> LDS staging rate, so the step
+// time follows the bytes staged per step rather than the MFMA count.
+static double gh_step_us(int mb, int nbw) {
+    if (mb == 16) return 1.21;                                       // 256 x 256, eight MFMA waves
+    const int code = mb * 10 + nbw;
+    switch (code) {
+        case 84: return 0.68;
+        case 44: return 0.46;
+        case 82: return 0.375;
+        case 42: return 0.242;
+        case 81: return 0.285;
+        case 41: return 0.168;
+        default: return 0.12;                                        // (2,1)
+    }
+}
 static double gh_cost(int mb, int nbw, int M, int N, int K, int num_cus, bool gelu) {
     const int BM = mb * 16, BN = nbw * 64;
     const double tiles = (double)((M + BM - 1) / BM) * (N / BN);
     const double rounds = (double)(long)((tiles + num_cus - 1) / num_cus);
-    const double mfma = (double)mb * nbw * 16.0;                     // cycles per K step per wave
-    const double mem = (double)(BM + BN) * 64.0 / 24.0;              // staging at ~24 B/clk/CU
-    const double step = (mfma > mem ? mfma : mem) + 60.0;
-    return rounds * ((K / 32) * step + mb * nbw * (gelu ? 160.0 : 30.0) + 600.0);
+    const double blocks = mb == 16 ? 32.0 : (double)mb * nbw;       // accumulator blocks per wave
+    return rounds * ((K / 32) * gh_step_us(mb, nbw) + blocks * (gelu ? 0.1 : 0.03) + 0.5);
 }
 
 int gemm2_num_cus();
@@ -325,6 +596,11 @@ hipError_t launch_gemmh(const GemmHParams& p, hipStream_t s) {
     }
     GH_CONFIGS(X)
 #undef X
+    const bool ok8 = p.K >= 128 && p.N % 256 == 0 && (size_t)4 * 32768 + (size_t)p.N * 4 <= 160 * 1024;
+    if (ok8 && (force_mb == 16 || (!force_mb && gh_cost(16, 4, p.M, p.N, p.K, num_cus, p.gelu != 0) < best))) {
+        if (debug) fprintf(stderr, "[gemmh] M=%d N=%d K=%d -> tile 256x256 (8 MFMA waves)\n", p.M, p.N, p.K);
+        return launch_cfg_h8(p, num_cus, s);
+    }
     if (!best_mb) return hipErrorNotSupported;
     if (debug) fprintf(stderr, "[gemmh] M=%d N=%d K=%d -> tile %dx%d\n", p.M, p.N, p.K, best_mb * 16, best_nbw * 64);
 #define X(mb, nbw, nst) \
