@@ -69,7 +69,7 @@ struct gdx_model {
     int d, J, ff, L, H;
     bool f16 = false;                 // cfg.compute_dtype == GDX_DTYPE_F16: fp16 MFMA operands, fp32 accumulate
     _Float16 *xt16 = nullptr, *xa16 = nullptr, *xb16 = nullptr, *qkv16 = nullptr, *ctx16 = nullptr, *ffb16 = nullptr,
-             *emb16 = nullptr, *xc16 = nullptr, *tmp16 = nullptr;
+             *emb16 = nullptr, *xc16 = nullptr, *tmp16 = nullptr, *xseq16 = nullptr;
     std::set<std::string> have;
     std::vector<std::string> required;
     std::vector<void*> allocs;        // weight allocations
@@ -372,7 +372,7 @@ extern "C" int gdx_prepare(gdx_handle_t h, int32_t batch, int32_t frames) {
         if (H16(&h->xt16, NT * round_up(h->J, 64)) || H16(&h->xa16, N * d) || H16(&h->xb16, N * d) ||
             H16(&h->qkv16, N * 3 * d) || H16(&h->ctx16, N * d) || H16(&h->tmp16, N * d) || H16(&h->ffb16, N * h->ff) || H16(&h->xc16, NT * d))
             return -1;
-        if (h->cfg.arch == GDX_ARCH_MDM && H16(&h->emb16, NT * d)) return -1;
+        if (h->cfg.arch == GDX_ARCH_MDM && (H16(&h->emb16, NT * d) || H16(&h->xseq16, NT * d))) return -1;
     }
     if (h->keep_taps) {
         h->taps.resize(h->L + 1);
@@ -556,10 +556,17 @@ static int forward_core_f16(gdx_model* h, const float* x, const float* temb, int
         if (gemm_f16(h->xt16, Jp, h->in_x, h->in_x.bias, nullptr, 0, nullptr, 0, nullptr, 0, h->emb16, d, Beff * T, d, T, 0, 0, s))
             return -1;
         HIPCHK(launch_small_linear(h->coa, d, h->proj_coa.w, h->proj_coa.kpad, nullptr, h->c2, d, Beff, d, d, 0, s));
-        if (gemm_f16(h->emb16, d, h->proj_pose, nullptr, h->addend, d, h->c2, d, h->xseq, d, nullptr, 0, Beff * T, d, T, 0, 0, s))
-            return -1;
-        HIPCHK(launch_local_attention(h->xseq, h->rope_cos, h->rope_sin, h->xa, h->xa16, Beff, T, d, h->cfg.cl_head,
-                                      h->cfg.window, s));
+        if (local_attention_f16_supported(d, h->cfg.cl_head, h->cfg.window)) {
+            if (gemm_f16(h->emb16, d, h->proj_pose, nullptr, h->addend, d, h->c2, d, nullptr, 0, h->xseq16, d, Beff * T, d, T, 0, 0, s))
+                return -1;
+            HIPCHK(launch_local_attention_f16(h->xseq16, h->rope_cos, h->rope_sin, h->xa16, tap32, Beff, T, d,
+                                              h->cfg.cl_head, h->cfg.window, s));
+        } else {
+            if (gemm_f16(h->emb16, d, h->proj_pose, nullptr, h->addend, d, h->c2, d, h->xseq, d, nullptr, 0, Beff * T, d, T, 0, 0, s))
+                return -1;
+            HIPCHK(launch_local_attention(h->xseq, h->rope_cos, h->rope_sin, h->xa, h->xa16, Beff, T, d, h->cfg.cl_head,
+                                          h->cfg.window, s));
+        }
     }
     if (h->keep_taps)
         HIPCHK(hipMemcpyAsync(h->taps[0], h->xa, sizeof(float) * (size_t)N * d, hipMemcpyDeviceToDevice, s));

@@ -100,6 +100,10 @@ hipError_t launch_local_attention(const float* xseq, const float* cosT, const fl
 // dst[i] = (fp16) src[i]
 hipError_t launch_convert_f16(const float* src, _Float16* dst, int64_t n, hipStream_t s);
 hipError_t launch_convert_f32(const _Float16* src, float* dst, int64_t n, hipStream_t s);
+// fp16-mode V2 front end on the fp16 MFMA (d / heads in {64, 128}); xseq in halves; enc32 optional (parity taps)
+bool local_attention_f16_supported(int d, int heads, int window);
+hipError_t launch_local_attention_f16(const _Float16* xseq, const float* cosT, const float* sinT, _Float16* enc16,
+                                      float* enc32, int B, int T, int d, int heads, int window, hipStream_t s);
 // out = u + scale[b]*(c - u)
 hipError_t launch_cfg_blend(const float* c, const float* u, const float* scale, float* out, int B,
                             int64_t per_sample, hipStream_t s);

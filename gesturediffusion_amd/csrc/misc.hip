@@ -478,6 +478,167 @@ hipError_t launch_local_attention(const float* xseq, const float* cosT, const fl
     return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------------------------
+// V2 front end of the fp16 mode (same maths as local_attention_kernel above) on the fp16 MFMA: one wave per
+// (sample, local head, window), four waves per block.  q = k = v = RoPE(x) for the <= 2*window rows involved:
+//   * each lane loads 8-half pieces of "its" row (row = lane & 15 of a 16-row block) for all head-dim steps, so both
+//     halves of every rotary pair sit in the same lane: RoPE is in-lane, and the rotated pieces are directly the
+//     MFMA fragments of S^T = K Q^T (K block 0, K block 1 and the query block are three such row blocks);
+//   * softmax on the accumulator layout (query on the lane axis, 8 keys per lane; cross-lane max / sum by two
+//     shuffles), probabilities rounded to fp16 = B operand of O^T += V^T P^T;
+//   * V^T fragments: the rotated key rows are parked in LDS (8 KiB per wave, chunk-swizzled like attentionh.hip)
+//     and read back with ds_read_b64_tr_b16;
+//   * second RoPE (position t+1) on the O^T accumulators, again in-lane; fp16 store into the encoder input.
+typedef _Float16 la_f16x8 __attribute__((ext_vector_type(8)));
+typedef __fp16 la_fp16x4_t __attribute__((__vector_size__(4 * sizeof(__fp16))));
+
+template <int E>
+__global__ __launch_bounds__(256) void local_attention_h_kernel(const _Float16* __restrict__ xseq,
+                                                                const float* __restrict__ cosT,
+                                                                const float* __restrict__ sinT,
+                                                                _Float16* __restrict__ enc16, float* __restrict__ enc32,
+                                                                int nwork, int T, int d, int heads, int window) {
+    constexpr int HALF = E / 2, NKS = E / 32, NNB = E / 16, ROWB = E * 2;
+    __shared__ __attribute__((aligned(16))) char sm_all[4 * 32 * ROWB];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int l15 = lane & 15, lq = lane >> 4;
+    int work = blockIdx.x * 4 + wave;
+    const bool active = work < nwork;
+    work = active ? work : nwork - 1;                 // surplus waves redo the last window (EXEC must stay full for the
+    char* sm = sm_all + wave * 32 * ROWB;             // transposed reads); they skip the stores
+    const int nwin = T / window;
+    const int w = work % nwin, head = (work / nwin) % heads, b = work / (nwin * heads);
+    const int k0 = w == 0 ? 0 : (w - 1) * window;
+    const int q0 = w * window;
+    const int nkeys = q0 + window - k0;               // window or 2*window (<= 32)
+    const _Float16* xb = xseq + ((long)b * T) * d + head * E;
+    auto fswz = [](int row) { return E == 64 ? ((row >> 1) & 3) << 1 : (row & 7) << 1; };
+
+    // rotated row -> NKS fragments (8 halves at head-dim 32*ks + 8*lq .. +7); rows past the sequence read row T-1
+    auto load_rot = [&](int pos, la_f16x8 (&f)[NKS]) {
+        const int pc = pos < T ? pos : T - 1;
+        const _Float16* row = xb + (long)pc * d + 8 * lq;
+        float v[NKS][8];
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+            const la_f16x8 h = *reinterpret_cast<const la_f16x8*>(row + 32 * ks);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[ks][j] = (float)h[j];
+        }
+#pragma unroll
+        for (int ks = 0; ks < NKS / 2; ++ks) {
+            const float* cp = cosT + (long)pc * HALF + 32 * ks + 8 * lq;
+            const float* sp = sinT + (long)pc * HALF + 32 * ks + 8 * lq;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float c = cp[j], s = sp[j];
+                const float lo = v[ks][j], hi = v[ks + NKS / 2][j];
+                v[ks][j] = lo * c - hi * s;
+                v[ks + NKS / 2][j] = hi * c + lo * s;
+            }
+        }
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks)
+            f[ks] = la_f16x8{(_Float16)v[ks][0], (_Float16)v[ks][1], (_Float16)v[ks][2], (_Float16)v[ks][3],
+                             (_Float16)v[ks][4], (_Float16)v[ks][5], (_Float16)v[ks][6], (_Float16)v[ks][7]};
+    };
+    la_f16x8 kf[2][NKS], qf[NKS];
+    load_rot(k0 + l15, kf[0]);
+    load_rot(k0 + 16 + l15, kf[1]);
+    load_rot(q0 + l15, qf);
+    // park the rotated key rows for the transposed V reads
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+            const int row = kb * 16 + l15;
+            *reinterpret_cast<la_f16x8*>(sm + row * ROWB + (((ks * 4 + lq) ^ fswz(row)) << 4)) = kf[kb][ks];
+        }
+    // S^T[key][query]
+    f32x4 s[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) s[kb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[kb][ks], qf[ks], s[kb], 0, 0, 0);
+    const float c_log2 = 1.4426950408889634f / sqrtf((float)E);
+    float v[8];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int kk = kb * 16 + 4 * lq + e;
+            float x = s[kb][e] * c_log2;
+            if (kk >= nkeys || k0 + kk > q0 + l15) x = -INFINITY;     // look-back padding / causal
+            v[kb * 4 + e] = x;
+            mx = fmaxf(mx, x);
+        }
+    mx = fmaxf(mx, __shfl_xor(mx, 16));
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    float sum = 0.0f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        v[j] = __builtin_amdgcn_exp2f(v[j] - mx);
+        sum += v[j];
+    }
+    sum += __shfl_xor(sum, 16);
+    sum += __shfl_xor(sum, 32);
+    const float inv = 1.0f / sum;
+    const la_f16x8 pf = la_f16x8{(_Float16)(v[0] * inv), (_Float16)(v[1] * inv), (_Float16)(v[2] * inv), (_Float16)(v[3] * inv),
+                                 (_Float16)(v[4] * inv), (_Float16)(v[5] * inv), (_Float16)(v[6] * inv), (_Float16)(v[7] * inv)};
+    __builtin_amdgcn_s_waitcnt(0xc07f);               // the wave's own LDS writes (no other wave touches its region)
+    // O^T[hd][query] += V^T P^T
+    const int vrow = 4 * lq + (l15 >> 2);
+    const int vbase = vrow * ROWB + ((fswz(vrow) >> 1) << 5) + (l15 & 3) * 8;
+    f32x4 o[NNB];
+#pragma unroll
+    for (int nb = 0; nb < NNB; ++nb) {
+        const la_fp16x4_t t0 = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) la_fp16x4_t*)(sm + (vbase ^ (nb << 5))));
+        const la_fp16x4_t t1 = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) la_fp16x4_t*)(sm + ((vbase + 16 * ROWB) ^ (nb << 5))));
+        const f16x4 v0 = __builtin_bit_cast(f16x4, t0), v1 = __builtin_bit_cast(f16x4, t1);
+        const la_f16x8 vf = la_f16x8{v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+        o[nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pf, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+    }
+    // second rotary at position t+1 (lane: query l15, head-dim 16nb + 4lq + e; partner block nb +- NNB/2), store
+    if (active && l15 < window) {
+        const int pos = q0 + l15 + 1;
+        const long orow = ((long)b * (T + 1) + pos) * d + head * E;
+#pragma unroll
+        for (int nb = 0; nb < NNB / 2; ++nb) {
+            const f32x4 c = *reinterpret_cast<const f32x4*>(cosT + (long)pos * HALF + 16 * nb + 4 * lq);
+            const f32x4 sn = *reinterpret_cast<const f32x4*>(sinT + (long)pos * HALF + 16 * nb + 4 * lq);
+            const f32x4 lo = o[nb], hi = o[nb + NNB / 2];
+            const f32x4 rl = lo * c - hi * sn, rh = hi * c + lo * sn;
+            *reinterpret_cast<f16x4*>(enc16 + orow + 16 * nb + 4 * lq) = f16x4{(_Float16)rl[0], (_Float16)rl[1], (_Float16)rl[2], (_Float16)rl[3]};
+            *reinterpret_cast<f16x4*>(enc16 + orow + 16 * (nb + NNB / 2) + 4 * lq) =
+                f16x4{(_Float16)rh[0], (_Float16)rh[1], (_Float16)rh[2], (_Float16)rh[3]};
+            if (enc32) {
+                *reinterpret_cast<f32x4*>(enc32 + orow + 16 * nb + 4 * lq) = rl;
+                *reinterpret_cast<f32x4*>(enc32 + orow + 16 * (nb + NNB / 2) + 4 * lq) = rh;
+            }
+        }
+    }
+}
+
+bool local_attention_f16_supported(int d, int heads, int window) {
+    const int e = d / heads;
+    return (e == 64 || e == 128) && window >= 1 && window <= 16 && d % 8 == 0;
+}
+
+hipError_t launch_local_attention_f16(const _Float16* xseq, const float* cosT, const float* sinT, _Float16* enc16,
+                                      float* enc32, int B, int T, int d, int heads, int window, hipStream_t s) {
+    const int e = d / heads;
+    const int nwork = B * heads * (T / window);
+    const dim3 grid((nwork + 3) / 4), block(256);
+    if (e == 128)
+        hipLaunchKernelGGL(local_attention_h_kernel<128>, grid, block, 0, s, xseq, cosT, sinT, enc16, enc32, nwork, T, d, heads, window);
+    else if (e == 64)
+        hipLaunchKernelGGL(local_attention_h_kernel<64>, grid, block, 0, s, xseq, cosT, sinT, enc16, enc32, nwork, T, d, heads, window);
+    else
+        return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+
 __global__ void convert_f16_kernel(const float* __restrict__ src, _Float16* __restrict__ dst, int64_t n) {
     const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
     if (i + 3 < n) {
