@@ -20,7 +20,7 @@ def load_model_wo_clip(model, state_dict):
 
 def create_model_and_diffusion(args, data=None):
     cls = MDM_Old if getattr(args, "arch_version", "mdm") == "mdm_old" else MDM
-    model = cls(**get_model_args(args, data))
+    model = cls(**get_model_args(args, data), compute_dtype=getattr(args, "compute_dtype", None))
     diffusion = create_gaussian_diffusion(args)
     return model, diffusion
 

@@ -128,6 +128,8 @@ def add_native_options(parser):
     group.add_argument("--rng", default='torch', choices=['torch', 'philox'],
                        help="torch = reference draw order; philox = fused in-kernel noise (shard invariant).")
     group.add_argument("--chunks", default=14, type=int, help="Autoregressive chunks per take (reference: 14).")
+    group.add_argument("--compute_dtype", default='fp32', choices=['fp32', 'fp16'],
+                       help="fp32 = exact fp32 MFMA (reference precision); fp16 = fp16 MFMA operands, fp32 accumulate.")
 
 
 def generate_args(argv=None):

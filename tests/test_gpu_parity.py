@@ -366,6 +366,7 @@ def test_error_behaviour_matches_reference(golden_dir):
 
 
 @pytest.mark.parametrize("extra", [["--arch_version", "mdm_old", "--num_frames", "23", "--guidance_param", "1"],
+                                   ["--arch_version", "mdm", "--num_frames", "20", "--compute_dtype", "fp16"],
                                    ["--arch_version", "mdm", "--num_frames", "20", "--rng", "philox"],
                                    ["--arch_version", "mdm", "--num_frames", "20", "--sampler", "ddim", "--timestep_respacing", "ddim10"]])
 def test_generate_cli_synthetic(tmp_path, extra):
@@ -391,7 +392,7 @@ F16_TOL = 2e-2
 
 
 @pytest.mark.parametrize("M,N,K,gelu", [(1000, 1024, 512, 0), (333, 320, 576, 0), (257, 1536, 512, 1), (64, 64, 64, 1),
-                                        (4100, 512, 1024, 0)])
+                                        (4100, 512, 1024, 0), (16000, 3072, 128, 1)])   # the last one takes the 256x256 kernel
 def test_fp16_gemm_vs_torch(M, N, K, gelu):
     """csrc/gemmh.hip through the C ABI: exact products of the fp16-rounded operands, fp32 accumulate -> the fp32
     output matches an fp64 reference on the same rounded operands to fp32 round-off; the fp16 output to fp16 round-off."""
@@ -411,8 +412,9 @@ def test_fp16_gemm_vs_torch(M, N, K, gelu):
     ref = A.half().double() @ W.half().double().t() + b.double()
     if gelu:
         ref = torch.nn.functional.gelu(ref)
-    assert rel_err(C32.cpu().double(), ref.cpu()) < (3e-5 if gelu else 2e-6)    # GELU: polynomial erf, |err| <= 1.1e-5 |x|
-    assert rel_err(C16.cpu().double(), ref.cpu()) < 1e-3
+    dev_err = lambda c: float(((c.double() - ref).abs().max() / ref.abs().max()).item())   # noqa: E731
+    assert dev_err(C32) < (3e-5 if gelu else 2e-6)    # GELU: polynomial erf, |err| <= 1.1e-5 |x|
+    assert dev_err(C16) < 1e-3
 
 
 @pytest.mark.parametrize("B,S,H,dm", [(2, 197, 4, 512), (1, 521, 4, 1024), (3, 250, 2, 128), (2, 31, 8, 512), (2, 1, 4, 512),
