@@ -18,7 +18,7 @@ EXPORTS = [
     "gdx_create", "gdx_destroy", "gdx_last_error", "gdx_set_weight", "gdx_weights_ready", "gdx_prepare",
     "gdx_set_condition", "gdx_forward", "gdx_set_keep_taps", "gdx_get_tap", "gdx_sampler_update", "gdx_q_sample",
     "gdx_randn", "gdx_sample_loop", "gdx_bench_ffn_gemm", "gdx_bench_gemm", "gdx_forward_flops", "gdx_profile_begin", "gdx_profile_end", "gdx_bench_attention",
-    "gdx_linear_f16", "gdx_bench_gemm_f16", "gdx_attention_f16",
+    "gdx_linear_f16", "gdx_bench_gemm_f16", "gdx_attention_f16", "gdx_plms_update",
 ]
 
 
@@ -39,6 +39,14 @@ class UpdateArgs(C.Structure):
         ("inpaint_mask", C.c_void_p), ("inpaint_motion", C.c_void_p), ("noise", C.c_void_p),
         ("const_noise", C.c_int32), ("philox_seed", C.c_uint64), ("sample_offset", C.c_uint64),
         ("rng_step", C.c_uint32), ("out", C.c_void_p), ("pred_xstart", C.c_void_p),
+    ]
+
+
+class PlmsArgs(C.Structure):
+    _fields_ = [
+        ("kind", C.c_int32), ("batch", C.c_int32), ("per_sample", C.c_int64), ("coef", C.c_void_p), ("t", C.c_void_p),
+        ("step_index", C.c_int32), ("x", C.c_void_p), ("pred_xstart", C.c_void_p), ("eps", C.c_void_p * 4),
+        ("out", C.c_void_p),
     ]
 
 
@@ -91,6 +99,7 @@ def load():
         "gdx_bench_gemm": [i32, i32, i32, i32, i32, C.POINTER(C.c_float), vp],
         "gdx_bench_attention": [i32, i32, i32, i32, i32, i32, C.POINTER(C.c_float), vp],
         "gdx_linear_f16": [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp],
+        "gdx_plms_update": [C.POINTER(PlmsArgs), vp],
         "gdx_attention_f16": [vp, vp, i32, i32, i32, i32, vp],
         "gdx_bench_gemm_f16": [i32, i32, i32, i32, i32, C.POINTER(C.c_float), vp],
         "gdx_profile_begin": [vp, i32],

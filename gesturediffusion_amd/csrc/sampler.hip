@@ -137,6 +137,44 @@ __global__ void q_sample_kernel(const float* __restrict__ xs, const float* __res
     out[i] = __fadd_rn(__fmul_rn(a, xs[i]), __fmul_rn(b, nz[i]));
 }
 
+// PLMS pieces (reference gaussian_diffusion.py:995-1079), every product / sum rounded separately in torch's op order.
+// coef row c = coef[t]: c[0] sqrt_recip_alphas_cumprod, c[1] sqrt_recipm1_alphas_cumprod, c[2] sqrt(alpha_bar_prev),
+// c[3] sqrt(1 - alpha_bar_prev), c[7] (t != 0).
+//   kind 0: eps_out = (c0*x - x0) / c1                                        (_predict_eps_from_xstart)
+//   kind 6: out = x0*c2 + c3*e0                                               (improved-Euler predictor)
+//   kind 1..5: eps' = e0 | (3e0 - e1)/2 | (23e0 - 16e1 + 5e2)/12 | (55e0 - 59e1 + 37e2 - 9e3)/24 | (e0 + e1)/2
+//              pred' = c0*x - c1*eps';  out = (pred'*c2 + c3*eps')*nz + x0*(1 - nz)
+__global__ void plms_kernel(int kind, const float* __restrict__ coef, const int64_t* __restrict__ t, int step_index,
+                            const float* __restrict__ x, const float* __restrict__ x0, const float* __restrict__ e0,
+                            const float* __restrict__ e1, const float* __restrict__ e2, const float* __restrict__ e3,
+                            float* __restrict__ out, long per_sample, long total) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const long idx = t ? (long)t[i / per_sample] : (long)step_index;
+    const float* c = coef + idx * 8;
+    if (kind == 0) {
+        out[i] = __fdiv_rn(__fsub_rn(__fmul_rn(c[0], x[i]), x0[i]), c[1]);
+        return;
+    }
+    if (kind == 6) {
+        out[i] = __fadd_rn(__fmul_rn(x0[i], c[2]), __fmul_rn(c[3], e0[i]));
+        return;
+    }
+    float ep;
+    if (kind == 1) ep = e0[i];
+    else if (kind == 2) ep = __fdiv_rn(__fsub_rn(__fmul_rn(3.0f, e0[i]), e1[i]), 2.0f);
+    else if (kind == 3)
+        ep = __fdiv_rn(__fadd_rn(__fsub_rn(__fmul_rn(23.0f, e0[i]), __fmul_rn(16.0f, e1[i])), __fmul_rn(5.0f, e2[i])), 12.0f);
+    else if (kind == 4)
+        ep = __fdiv_rn(__fsub_rn(__fadd_rn(__fsub_rn(__fmul_rn(55.0f, e0[i]), __fmul_rn(59.0f, e1[i])), __fmul_rn(37.0f, e2[i])),
+                                 __fmul_rn(9.0f, e3[i])), 24.0f);
+    else ep = __fdiv_rn(__fadd_rn(e0[i], e1[i]), 2.0f);
+    const float pred = __fsub_rn(__fmul_rn(c[0], x[i]), __fmul_rn(c[1], ep));
+    const float mean = __fadd_rn(__fmul_rn(pred, c[2]), __fmul_rn(c[3], ep));
+    const float nz = c[7];
+    out[i] = __fadd_rn(__fmul_rn(mean, nz), __fmul_rn(x0[i], __fsub_rn(1.0f, nz)));
+}
+
 __global__ void randn_kernel(float* __restrict__ out, int batch, long per_sample, long groups, uint64_t seed,
                              uint64_t sample_offset, uint32_t step) {
     const long gid = (long)blockIdx.x * 256 + threadIdx.x;
@@ -203,6 +241,23 @@ extern "C" int gdx_q_sample(const float* x_start, const float* noise, const floa
     hipLaunchKernelGGL(gdx::q_sample_kernel, dim3((count + 255) / 256), dim3(256), 0, (hipStream_t)stream, x_start,
                        noise, coef, idx, (long)count, out);
     return hipGetLastError() == hipSuccess ? 0 : gdx_set_error_("gdx_q_sample: launch failed");
+}
+
+extern "C" int gdx_plms_update(const gdx_plms_args_t* a, void* stream) {
+    if (!a || !a->coef || !a->out) return gdx_set_error_("gdx_plms_update: null argument");
+    if (a->kind < 0 || a->kind > 6) return gdx_set_error_("gdx_plms_update: bad kind");
+    const int k = a->kind;
+    const bool need_x = k != 6, need_x0 = true, need_e0 = k != 0, need_e1 = k == 2 || k == 3 || k == 4 || k == 5,
+               need_e2 = k == 3 || k == 4, need_e3 = k == 4;
+    if ((need_x && !a->x) || (need_x0 && !a->pred_xstart) || (need_e0 && !a->eps[0]) || (need_e1 && !a->eps[1]) ||
+        (need_e2 && !a->eps[2]) || (need_e3 && !a->eps[3]))
+        return gdx_set_error_("gdx_plms_update: missing operand for this kind");
+    const long total = (long)a->batch * a->per_sample;
+    if (total <= 0) return 0;
+    hipLaunchKernelGGL(gdx::plms_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, k, a->coef, a->t,
+                       a->step_index, a->x, a->pred_xstart, a->eps[0], a->eps[1], a->eps[2], a->eps[3], a->out,
+                       (long)a->per_sample, total);
+    return hipGetLastError() == hipSuccess ? 0 : gdx_set_error_("gdx_plms_update: launch failed");
 }
 
 extern "C" int gdx_randn(float* out, int32_t batch, int64_t per_sample, uint64_t philox_seed, uint64_t sample_offset,

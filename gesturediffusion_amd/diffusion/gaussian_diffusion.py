@@ -162,6 +162,7 @@ class GaussianDiffusion:
             c[:, 4] = 0.0
         c[:, 5] = f32(self.sqrt_alphas_cumprod)
         c[:, 6] = f32(self.sqrt_one_minus_alphas_cumprod)
+        c[:, 7] = nz                                      # (t != 0), used by the PLMS update
         c = c.to(device)
         self._coef_cache[key] = c
         return c
@@ -402,8 +403,75 @@ class GaussianDiffusion:
     def training_losses(self, *a, **k):
         raise NotImplementedError("training is outside the sampling hot path (SURVEY.md section 2.1)")
 
-    def plms_sample_loop(self, *a, **k):
-        raise NotImplementedError("PLMS sampling is listed as 'next' (SURVEY.md 8f N4)")
+    # ------------------------------------------------------------------ PLMS (reference :995-1190)
+    def _pred_xstart(self, model, x, t, clip_denoised, denoised_fn, model_kwargs):
+        """p_mean_variance's pred_xstart (model output after CFG / inpainting / clipping)."""
+        return self._step(GDX_SAMPLER_P, model, x, t, clip_denoised, denoised_fn, None, model_kwargs,
+                          noise=th.zeros_like(x))["pred_xstart"]
+
+    def plms_sample(self, model, x, t, clip_denoised=True, denoised_fn=None, cond_fn=None, model_kwargs=None,
+                    cond_fn_with_grad=False, order=2, old_out=None):
+        """Pseudo linear multistep step (reference :995-1079): eps from the x0 prediction, pseudo improved Euler on
+        the first step (one extra model call at t-1), Adams-Bashforth of order <= `order` afterwards.  The
+        element-wise arithmetic runs in gdx_plms_update with the reference's op order."""
+        if not int(order) or not 1 <= order <= 4:
+            raise ValueError('order is invalid (should be int from 1-4).')
+        if cond_fn is not None or cond_fn_with_grad:
+            raise NotImplementedError("cond_fn guidance is outside the sampling hot path (SURVEY.md 8f N4)")
+        coef = self.coef_table(GDX_SAMPLER_DDIM, x.device, 0.0)
+        xc = E.f32c(x, "x")
+        tt = t.to(th.int64).contiguous()
+        x0 = self._pred_xstart(model, xc, tt, clip_denoised, denoised_fn, model_kwargs)
+        eps = E.plms_update(0, coef, tt, xc, x0)
+        if order > 1 and old_out is None:
+            old_eps = [eps]
+            mean_pred = E.plms_update(6, coef, tt, None, x0, eps=[eps])
+            t2 = (tt - 1) % self.num_timesteps            # t - 1 (a negative index wraps in the reference's table gather)
+            x0_2 = self._pred_xstart(model, mean_pred, t2, clip_denoised, denoised_fn, model_kwargs)
+            eps_2 = E.plms_update(0, coef, t2, mean_pred, x0_2)
+            sample = E.plms_update(5, coef, tt, xc, x0, eps=[eps, eps_2])
+        else:
+            old_eps = old_out["old_eps"]                  # TypeError on the first step with order == 1, like the reference
+            old_eps.append(eps)
+            cur = min(order, len(old_eps))
+            sample = E.plms_update(cur, coef, tt, xc, x0, eps=old_eps[::-1][:cur])
+        if len(old_eps) >= order:
+            old_eps.pop(0)
+        return {"sample": sample, "pred_xstart": x0, "old_eps": old_eps}
+
+    def plms_sample_loop(self, model, shape, noise=None, clip_denoised=True, denoised_fn=None, cond_fn=None,
+                         model_kwargs=None, device=None, progress=False, skip_timesteps=0, init_image=None,
+                         randomize_class=False, cond_fn_with_grad=False, order=2):
+        final = None
+        for sample in self.plms_sample_loop_progressive(model, shape, noise=noise, clip_denoised=clip_denoised,
+                                                        denoised_fn=denoised_fn, cond_fn=cond_fn,
+                                                        model_kwargs=model_kwargs, device=device, progress=progress,
+                                                        skip_timesteps=skip_timesteps, init_image=init_image,
+                                                        randomize_class=randomize_class,
+                                                        cond_fn_with_grad=cond_fn_with_grad, order=order):
+            final = sample
+        return final["sample"]
+
+    def plms_sample_loop_progressive(self, model, shape, noise=None, clip_denoised=True, denoised_fn=None,
+                                     cond_fn=None, model_kwargs=None, device=None, progress=False, skip_timesteps=0,
+                                     init_image=None, randomize_class=False, cond_fn_with_grad=False, order=2):
+        if randomize_class:
+            raise NotImplementedError("randomize_class is outside the sampling hot path")
+        device, img, indices = self._prepare_loop(model, shape, noise, device, skip_timesteps, init_image, "torch", 0,
+                                                  0, None)
+        if progress:
+            from tqdm.auto import tqdm
+            indices = tqdm(indices)
+        old_out = None
+        for i in indices:
+            t = th.full((shape[0],), i, device=device, dtype=th.long)
+            with th.no_grad():
+                out = self.plms_sample(model, img, t, clip_denoised=clip_denoised, denoised_fn=denoised_fn,
+                                       cond_fn=cond_fn, model_kwargs=model_kwargs,
+                                       cond_fn_with_grad=cond_fn_with_grad, order=order, old_out=old_out)
+            yield out
+            old_out = out
+            img = out["sample"]
 
 
 def _extract_into_tensor(arr, timesteps, broadcast_shape):

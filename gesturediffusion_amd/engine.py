@@ -175,6 +175,21 @@ def sampler_update(kind, coef, x, x0_cond, out, t=None, step_index=0, x0_uncond=
     return out
 
 
+def plms_update(kind, coef, t, x, pred_xstart, eps=(), out=None):
+    """gdx_plms_update: kind 0 eps, 6 Euler predictor, 1..4 Adams-Bashforth, 5 Euler corrector (include/gdx.h)."""
+    lib = _lib.load()
+    ref = pred_xstart
+    if out is None:
+        out = torch.empty_like(ref)
+    a = _lib.PlmsArgs(kind=kind, batch=ref.shape[0], per_sample=ref.numel() // ref.shape[0], coef=coef.data_ptr(),
+                      t=t.data_ptr(), step_index=0, x=x.data_ptr() if x is not None else None,
+                      pred_xstart=pred_xstart.data_ptr(), out=out.data_ptr())
+    for i, e in enumerate(eps):
+        a.eps[i] = e.data_ptr()
+    _lib.check(lib.gdx_plms_update(C.byref(a), _stream(ref.device)), lib)
+    return out
+
+
 def q_sample(x_start, noise, coef, idx):
     lib = _lib.load()
     out = torch.empty_like(x_start)

@@ -135,6 +135,29 @@ typedef struct {
 } gdx_update_args_t;
 int gdx_sampler_update(const gdx_update_args_t* a, void* stream);
 
+/* PLMS building blocks (plms_sample, gaussian_diffusion.py:995-1079), element-wise over [B, per_sample] with
+ * separately rounded products / sums in the reference's op order.  coef rows as for gdx_sampler_update with the
+ * DDIM layout (c[0] sqrt_recip_alphas_cumprod, c[1] sqrt_recipm1_alphas_cumprod, c[2] sqrt(alpha_bar_prev),
+ * c[3] sqrt(1 - alpha_bar_prev)) plus c[7] = (t != 0).  idx = t[b] if t != NULL else step_index.
+ *   kind 0: out = eps = (c0*x - pred_xstart) / c1                      (_predict_eps_from_xstart :407-411)
+ *   kind 6: out = pred_xstart*c2 + c3*eps[0]                           (pseudo improved Euler predictor :1048)
+ *   kind 1..4: Adams-Bashforth of that order over eps[0] (newest) .. eps[3]   (:1060-1069)
+ *   kind 5: eps' = (eps[0] + eps[1]) / 2                               (improved Euler corrector :1050)
+ *   kinds 1..5 then: pred' = c0*x - c1*eps';  out = (pred'*c2 + c3*eps')*nz + pred_xstart*(1 - nz)   (:1051-1077) */
+typedef struct {
+    int32_t kind;
+    int32_t batch;
+    int64_t per_sample;
+    const float* coef;         /* [num_steps][8] */
+    const int64_t* t;          /* [B] or NULL */
+    int32_t step_index;
+    const float* x;            /* x_t (unused by kind 6) */
+    const float* pred_xstart;  /* model x0 after CFG / inpainting */
+    const float* eps[4];       /* eps history, newest first (unused by kind 0) */
+    float* out;
+} gdx_plms_args_t;
+int gdx_plms_update(const gdx_plms_args_t* a, void* stream);
+
 /* q_sample (gaussian_diffusion.py:233-251): out = a*x_start + b*noise, a/b per-sample from
  * coef rows (c[5], c[6]) at idx. */
 int gdx_q_sample(const float* x_start, const float* noise, const float* coef, int32_t idx,

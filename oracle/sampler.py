@@ -87,3 +87,66 @@ def sample_loop(model_fn, tab, tmap, shape, tape, y, kind="p", eta=0.0, skip_tim
         if dump_steps is not None and k in dump_steps:
             dump.append(img.clone())
     return dump if dump_steps is not None else img
+
+
+# ---------------------------------------------------------------------------------------------
+# PLMS (reference gaussian_diffusion.py:995-1190), for the configured mode START_X.
+def predict_eps(tab, x0, x, t):
+    """_predict_eps_from_xstart :407-411."""
+    return (extract(tab.sqrt_recip_alphas_cumprod, t) * x - x0) / extract(tab.sqrt_recipm1_alphas_cumprod, t)
+
+
+def predict_xstart(tab, eps, x, t):
+    """_predict_xstart_from_eps :390-396."""
+    return extract(tab.sqrt_recip_alphas_cumprod, t) * x - extract(tab.sqrt_recipm1_alphas_cumprod, t) * eps
+
+
+def plms_step(x0_fn, tab, x, t, order, old_eps):
+    """plms_sample :995-1079.  x0_fn(x, t) -> model x0 prediction after the inpainting blend (p_mean_variance).
+    old_eps: list carried between steps (None on the first step).  Returns (sample, pred_xstart, old_eps)."""
+    if not int(order) or not 1 <= order <= 4:
+        raise ValueError('order is invalid (should be int from 1-4).')
+    ab_prev = extract(tab.alphas_cumprod_prev, t)
+    x0 = x0_fn(x, t)
+    eps = predict_eps(tab, x0, x, t)
+    if order > 1 and old_eps is None:
+        old_eps = [eps]                                                       # pseudo improved Euler
+        mean_pred = x0 * torch.sqrt(ab_prev) + torch.sqrt(1 - ab_prev) * eps
+        eps_2 = predict_eps(tab, x0_fn(mean_pred, t - 1), mean_pred, t - 1)
+        eps_prime = (eps + eps_2) / 2
+    else:
+        if old_eps is None:                                                   # order == 1 on the first step: the reference
+            raise TypeError("'NoneType' object is not subscriptable")         # subscripts old_out = None (:1057)
+        old_eps.append(eps)
+        cur = min(order, len(old_eps))
+        if cur == 1:
+            eps_prime = old_eps[-1]
+        elif cur == 2:
+            eps_prime = (3 * old_eps[-1] - old_eps[-2]) / 2
+        elif cur == 3:
+            eps_prime = (23 * old_eps[-1] - 16 * old_eps[-2] + 5 * old_eps[-3]) / 12
+        else:
+            eps_prime = (55 * old_eps[-1] - 59 * old_eps[-2] + 37 * old_eps[-3] - 9 * old_eps[-4]) / 24
+    pred_prime = predict_xstart(tab, eps_prime, x, t)
+    mean_pred = pred_prime * torch.sqrt(ab_prev) + torch.sqrt(1 - ab_prev) * eps_prime
+    if len(old_eps) >= order:
+        old_eps.pop(0)
+    nonzero = (t != 0).float().view(-1, 1, 1, 1)
+    return mean_pred * nonzero + x0 * (1 - nonzero), x0, old_eps
+
+
+def plms_loop(model_fn, tab, tmap, shape, x_T, y, order=2, skip_timesteps=0, init_image=None):
+    """plms_sample_loop_progressive :1121-1190 (deterministic given x_T)."""
+    B = shape[0]
+    img = x_T
+    if skip_timesteps and init_image is None:
+        init_image = torch.zeros_like(img)
+    indices = list(range(tab.num_timesteps - skip_timesteps))[::-1]
+    if init_image is not None:
+        img = q_sample(tab, init_image, torch.ones(B, dtype=torch.long) * indices[0], img)
+    map_tensor = torch.tensor(tmap, dtype=torch.long)
+    x0_fn = lambda x, t: inpaint(model_fn(x, map_tensor[t], y), y)   # noqa: E731
+    old = None
+    for i in indices:
+        img, _, old = plms_step(x0_fn, tab, img, torch.tensor([i] * B), order, old)
+    return img

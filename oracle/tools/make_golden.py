@@ -250,6 +250,46 @@ def gen_loops_tiny(mods, out):
         np.savez_compressed(os.path.join(out, f"loops_{arch}_tiny.npz"), **d)
 
 
+def gen_plms_tiny(mods, out):
+    """plms_sample_loop (gaussian_diffusion.py:995-1190) on the same tiny models / inputs as gen_loops_tiny
+    (outputs only; weights and inputs are read from loops_{arch}_tiny.npz by the tests)."""
+    ref_cfg, gd, rs = mods[2], mods[3], mods[4]
+    for arch in ("mdm", "mdm_old"):
+        cfg = tiny_cfg(arch)
+        sd = init_state_dict(cfg, seed=2, perturb=True)
+        B, T = 3, 20
+        _, seedp, mfcc = synthetic_inputs(cfg, B, T, seed=5)
+        m = build_ref_model(mods, cfg, sd)
+        cfgm = ref_cfg.ClassifierFreeSampleModel(m)
+        g = torch.Generator().manual_seed(1234)
+        shape = (B, cfg["njoints"], 1, T)
+        tape = torch.randn(22, *shape, generator=g)
+        init_image = torch.randn(*shape, generator=g)
+        mask = torch.zeros(shape, dtype=torch.bool)
+        mask[..., :5] = True
+        mask[:, :4] = True
+        motion = torch.randn(*shape, generator=g)
+        scale = torch.tensor([2.5, 1.0, 0.0])
+        y = {"seed": seedp, "mfcc": mfcc}
+        d = {}
+
+        def run(model, yy, **kw):
+            df = make_diffusion(gd, rs, [10])
+            return df.plms_sample_loop(model, shape, noise=tape[0].clone(), clip_denoised=False, model_kwargs={"y": yy},
+                                       progress=False, **kw).numpy()
+        d["plms10_o2"] = run(m, y)
+        d["plms10_o3"] = run(m, y, order=3)
+        d["plms10_o4_cfg"] = run(cfgm, dict(y, scale=scale), order=4)
+        d["plms10_o2_inpaint"] = run(m, dict(y, inpainting_mask=mask, inpainted_motion=motion))
+        d["plms10_o2_init_skip"] = run(m, y, init_image=init_image, skip_timesteps=3)
+        try:
+            run(m, y, order=1)
+            d["plms_order1_error"] = np.array("none")
+        except Exception as e:  # noqa: BLE001
+            d["plms_order1_error"] = np.array(type(e).__name__)
+        np.savez_compressed(os.path.join(out, f"plms_{arch}_tiny.npz"), **d)
+
+
 def gen_real_shapes(mods, out):
     """F4: outputs only; weights/inputs regenerate from gesturediffusion_amd.utils.init."""
     cases = {
@@ -332,16 +372,15 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--ref", default="/root/reference")
     ap.add_argument("--out", default=os.path.join(REPO, "tests", "golden"))
+    ap.add_argument("--only", default="", help="comma-separated subset: schedule,forward,loops,plms,real,negative,keys")
     args = ap.parse_args()
     os.makedirs(args.out, exist_ok=True)
     torch.set_num_threads(8)
     mods = import_reference(args.ref)
-    gen_schedule(mods, args.out)
-    gen_forward_tiny(mods, args.out)
-    gen_loops_tiny(mods, args.out)
-    gen_real_shapes(mods, args.out)
-    gen_negative(mods, args.out)
-    gen_state_dict_keys(mods, args.out)
+    gens = {"schedule": gen_schedule, "forward": gen_forward_tiny, "loops": gen_loops_tiny, "plms": gen_plms_tiny,
+            "real": gen_real_shapes, "negative": gen_negative, "keys": gen_state_dict_keys}
+    for name in (args.only.split(",") if args.only else gens):
+        gens[name](mods, args.out)
     for f in sorted(os.listdir(args.out)):
         print(f, os.path.getsize(os.path.join(args.out, f)))
 

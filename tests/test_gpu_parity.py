@@ -469,3 +469,73 @@ def test_fp16_mode_real_shapes_vs_reference_golden(name, arch, J, dm):
 def test_fp16_mode_loops_vs_reference_golden(arch, name):
     """fp16 mode through whole sampling loops (fused C++ loop) against the reference's fp32 loops, same noise tape."""
     _run_loop_case(arch, name, True, "fp16", F16_TOL)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# PLMS (SURVEY 8f N4): reference gaussian_diffusion.py:995-1190
+def _plms_oracle_step(tab, kind, x, x0, t, eps):
+    from oracle import sampler as osamp
+    ex = osamp.extract
+    if kind == 0:
+        return osamp.predict_eps(tab, x0, x, t)
+    abp = ex(tab.alphas_cumprod_prev, t)
+    if kind == 6:
+        return x0 * torch.sqrt(abp) + torch.sqrt(1 - abp) * eps[0]
+    ep = {1: lambda: eps[0], 2: lambda: (3 * eps[0] - eps[1]) / 2,
+          3: lambda: (23 * eps[0] - 16 * eps[1] + 5 * eps[2]) / 12,
+          4: lambda: (55 * eps[0] - 59 * eps[1] + 37 * eps[2] - 9 * eps[3]) / 24,
+          5: lambda: (eps[0] + eps[1]) / 2}[kind]()
+    pred = osamp.predict_xstart(tab, ep, x, t)
+    mean = pred * torch.sqrt(abp) + torch.sqrt(1 - abp) * ep
+    nz = (t != 0).float().view(-1, 1, 1, 1)
+    return mean * nz + x0 * (1 - nz)
+
+
+@pytest.mark.parametrize("kind", [0, 1, 2, 3, 4, 5, 6])
+def test_plms_update_bit_exact(kind):
+    """gdx_plms_update against the torch-CPU expression of the reference, same operands: identical bits."""
+    from gesturediffusion_amd import engine as E
+    from oracle import schedule as osch
+    tab, _ = osch.make_tables("cosine", 1000, [10])
+    df = _diffusion([10])
+    d = dev()
+    g = torch.Generator().manual_seed(kind)
+    shape = (5, 7, 1, 13)
+    x, x0 = torch.randn(shape, generator=g), torch.randn(shape, generator=g)
+    eps = [torch.randn(shape, generator=g) for _ in range(4)]
+    t = torch.tensor([0, 1, 5, 9, 0])
+    want = _plms_oracle_step(tab, kind, x, x0, t, eps)
+    coef = df.coef_table(1, d, 0.0)
+    got = E.plms_update(kind, coef, t.to(d), x.to(d), x0.to(d), eps=[e.to(d) for e in eps])
+    assert torch.equal(got.cpu(), want)
+
+
+@pytest.mark.parametrize("arch", ["mdm", "mdm_old"])
+@pytest.mark.parametrize("name,order", [("plms10_o2", 2), ("plms10_o3", 3), ("plms10_o4_cfg", 4), ("plms10_o2_inpaint", 2),
+                                        ("plms10_o2_init_skip", 2)])
+def test_plms_loops_vs_reference_golden(arch, name, order):
+    from gesturediffusion_amd.model.cfg_sampler import ClassifierFreeSampleModel
+    g = load_golden(f"loops_{arch}_tiny.npz")
+    gp = load_golden(f"plms_{arch}_tiny.npz")
+    d = dev()
+    m = build_model(arch, TINY, weights_from(g))
+    y = {"seed": torch.from_numpy(g["seed"]).to(d), "mfcc": torch.from_numpy(g["mfcc"]).to(d)}
+    model, kw = m, {}
+    if "cfg" in name:
+        y["scale"] = torch.from_numpy(g["scale"]).to(d)
+        model = ClassifierFreeSampleModel(m)
+    if "inpaint" in name:
+        y["inpainting_mask"] = torch.from_numpy(g["inpainting_mask"]).to(d)
+        y["inpainted_motion"] = torch.from_numpy(g["inpainted_motion"]).to(d)
+    if "init" in name:
+        kw.update(init_image=torch.from_numpy(g["init_image"]).to(d), skip_timesteps=3)
+    x_T = torch.from_numpy(g["tape"])[0].to(d)
+    df = _diffusion([10])
+    r = df.plms_sample_loop(model, tuple(x_T.shape), noise=x_T.clone(), clip_denoised=False, model_kwargs={"y": y},
+                            order=order, **kw)
+    # the multistep weights amplify fp32 forward differences (oracle vs reference measures 1.1e-4 at order 4 + CFG)
+    assert rel_err(r.cpu(), gp[name]) < (2e-3 if order == 4 else LOOP_TOL), name
+    with pytest.raises(TypeError):      # order 1 subscripts old_out = None on the first step, like the reference
+        df.plms_sample_loop(model, tuple(x_T.shape), noise=x_T.clone(), clip_denoised=False, model_kwargs={"y": y}, order=1)
+    with pytest.raises(ValueError):
+        df.plms_sample_loop(model, tuple(x_T.shape), noise=x_T.clone(), clip_denoised=False, model_kwargs={"y": y}, order=5)

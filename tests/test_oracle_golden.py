@@ -127,6 +127,42 @@ def test_loops_tiny(arch, name):
     assert rel_err(r, g[name]) < 2e-5, name
 
 
+PLMS = {"plms10_o2": (2, {}), "plms10_o3": (3, {}), "plms10_o4_cfg": (4, {}), "plms10_o2_inpaint": (2, {}),
+        "plms10_o2_init_skip": (2, {"skip_timesteps": 3})}
+
+
+@pytest.mark.parametrize("arch", ["mdm", "mdm_old"])
+@pytest.mark.parametrize("name", sorted(PLMS))
+def test_plms_tiny(arch, name):
+    """plms_sample_loop (reference gaussian_diffusion.py:995-1190), orders 2-4, CFG, inpainting, init_image + skip."""
+    g = load_golden(f"loops_{arch}_tiny.npz")
+    gp = load_golden(f"plms_{arch}_tiny.npz")
+    p = weights_from(g)
+    cfg = dict(TINY, arch=arch)
+    y = {"seed": torch.from_numpy(g["seed"]), "mfcc": torch.from_numpy(g["mfcc"])}
+    order, kw = PLMS[name]
+    kw = dict(kw)
+    if "cfg" in name:
+        y["scale"] = torch.from_numpy(g["scale"])
+        fn = lambda x, t, yy: omf.cfg_forward(p, cfg, x, t, yy)   # noqa: E731
+    else:
+        fn = lambda x, t, yy: omf.forward(p, cfg, x, t, yy)       # noqa: E731
+    if "inpaint" in name:
+        y["inpainting_mask"] = torch.from_numpy(g["inpainting_mask"])
+        y["inpainted_motion"] = torch.from_numpy(g["inpainted_motion"])
+    if "init" in name:
+        kw["init_image"] = torch.from_numpy(g["init_image"])
+    tab, tmap = osch.make_tables("cosine", 1000, [10])
+    x_T = torch.from_numpy(g["tape"])[0]
+    with torch.no_grad():
+        r = osamp.plms_loop(fn, tab, tmap, x_T.shape, x_T, y, order=order, **kw)
+    # the multistep weights (55, -59, 37, -9) / 24 amplify the fp32 forward differences; order 4 + CFG measures 1.1e-4
+    assert rel_err(r, gp[name]) < (5e-4 if order == 4 else 5e-5), name
+    assert str(gp["plms_order1_error"]) == "TypeError"
+    with pytest.raises(TypeError):
+        osamp.plms_loop(fn, tab, tmap, x_T.shape, x_T, y, order=1)
+
+
 @pytest.mark.parametrize("arch", ["mdm", "mdm_old"])
 def test_ddim_reverse_tiny(arch):
     g = load_golden(f"loops_{arch}_tiny.npz")
