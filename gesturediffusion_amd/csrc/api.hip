@@ -89,6 +89,9 @@ struct gdx_model {
     float *xt = nullptr, *xc = nullptr, *x0t = nullptr;   // token-major pose in / compacted last layer / token-major x0
     int ldo = 0;                      // row stride of x0t = J rounded up to 64
     float* temb_table = nullptr; int temb_table_rows = 0;
+    float* c2t_table = nullptr;       // V2: W_coa * temb_table rows (valid while c2t_valid)
+    float* c2_seed = nullptr;         // V2: W_coa * seed_cat rows [2B, d]
+    bool c2t_valid = false;
     int64_t* tmap_dev = nullptr;
     bool prof = false;                // in-situ FFN-1 GEMM timing (gdx_profile_begin / gdx_profile_end)
     std::vector<hipEvent_t> prof_ev;  // pairs, recorded around each FFN-1 launch while prof is on
@@ -316,6 +319,7 @@ extern "C" int gdx_set_weight(gdx_handle_t h, const char* name_c, const float* p
     if (rc) return rc;
     h->have.insert(name);
     h->cond_set = false;
+    h->c2t_valid = false;
     return 0;
 }
 
@@ -339,7 +343,7 @@ extern "C" int gdx_prepare(gdx_handle_t h, int32_t batch, int32_t frames) {
     if (h->B == batch && h->T == frames) return 0;
     free_pool(h->ws_allocs);
     h->taps.clear();
-    h->temb_table = nullptr; h->temb_table_rows = 0; h->tmap_dev = nullptr;
+    h->temb_table = nullptr; h->temb_table_rows = 0; h->tmap_dev = nullptr; h->c2t_table = nullptr; h->c2t_valid = false;
     h->B = batch; h->T = frames; h->S = frames + 1; h->cond_set = false;
     // +128 rows: the persistent GEMM reads / stores whole tiles past the last logical row (gemm2.hip)
     const size_t B2 = 2 * (size_t)batch, N = B2 * h->S + 128, d = h->d;
@@ -352,6 +356,7 @@ extern "C" int gdx_prepare(gdx_handle_t h, int32_t batch, int32_t frames) {
     };
     if (A(&h->xa, N * d) || A(&h->addend, N * d) || A(&h->seed_cat, B2 * d) || A(&h->temb_in, B2 * d) ||
         A(&h->temb_h, B2 * d) || A(&h->temb, B2 * d) || A(&h->coa, B2 * d) || A(&h->c2, (B2 + 1) * d) ||
+        A(&h->c2_seed, B2 * d) ||
         A(&h->x0, B2 * h->J * (size_t)frames))
         return -1;
     // fp32 activation buffers of the fp32 mode (the fp16 mode keeps its stream in the *16 buffers below)
@@ -424,6 +429,8 @@ extern "C" int gdx_set_condition(gdx_handle_t h, const float* seed, const float*
         // audio_term[b*T+t, :] = W_proj[:, d:d+26] mfcc[b,:,t] + b_proj     (model/mdm.py:151-169)
         HIPCHK(launch_mfcc_project(mfcc, h->proj_audio.w, h->proj_audio.kpad, h->proj_pose.bias, nullptr, h->addend,
                                    2 * B, B, h->cfg.mfcc_dim, T, d, T, 0, s));
+        // seed half of the coarse slice of project_to_lat (model/mdm.py:154-169), cond and uncond rows
+        HIPCHK(launch_small_linear(h->seed_cat, d, h->proj_coa.w, h->proj_coa.kpad, nullptr, h->c2_seed, d, 2 * B, d, d, 0, s));
     }
     h->cond_set = true;
     return 0;
@@ -467,15 +474,21 @@ static int forward_core(gdx_model* h, const float* x, const float* temb, int tst
     const int Jp = h->in_x.kpad;
     HIPCHK(launch_transpose_in(x, h->xt, Beff, B, J, T, Jp, s));
     if (h->cfg.arch == GDX_ARCH_MDM_OLD) {
-        HIPCHK(launch_token0(temb, tstride, seed_emb, h->pe, h->xa, nullptr, nullptr, Beff, B, S, d, s));
+        HIPCHK(launch_token0(temb, tstride, seed_emb, h->pe, h->xa, nullptr, nullptr, nullptr, nullptr, nullptr, Beff, B, S, d, s));
         // frames -> rows (b, t+1) of the encoder input, + hoisted MFCC/bias/PE term      (model/mdm_old.py:104-112)
         p = GemmParams{h->xt, Jp, h->in_x.w, h->in_x.kpad, nullptr, h->addend, d, nullptr, 0, h->xa, d, Beff * T, d, Jp, T, B};
         if (gemm(A_ROWS, B_WEIGHT, OUT_TOKROWS, EPI_RES, p, s)) return -1;
     } else {
-        HIPCHK(launch_token0(temb, tstride, seed_emb, nullptr, h->xa, nullptr, h->coa, Beff, B, S, d, s));
+        // inside a sampling loop the coarse slice of project_to_lat is table row + per-sample vector (see gdx_sample_loop)
+        const bool hoist = h->c2t_valid && tstride == 0 && temb >= h->temb_table &&
+                           temb < h->temb_table + (size_t)h->temb_table_rows * d;
+        const float* c2t_row = hoist ? h->c2t_table + (temb - h->temb_table) : nullptr;
+        const float* c2s = mode == GDX_UNCOND ? h->c2_seed + (size_t)B * d : h->c2_seed;
+        HIPCHK(launch_token0(temb, tstride, seed_emb, nullptr, h->xa, nullptr, h->coa, c2t_row, c2s, hoist ? h->c2 : nullptr,
+                             Beff, B, S, d, s));
         p = GemmParams{h->xt, Jp, h->in_x.w, h->in_x.kpad, h->in_x.bias, nullptr, 0, nullptr, 0, h->emb_pose, d, Beff * T, d, Jp, T, B};
         if (gemm(A_ROWS, B_WEIGHT, OUT_ROWS, EPI_BIAS, p, s)) return -1;
-        HIPCHK(launch_small_linear(h->coa, d, h->proj_coa.w, h->proj_coa.kpad, nullptr, h->c2, d, Beff, d, d, 0, s));
+        if (!hoist) HIPCHK(launch_small_linear(h->coa, d, h->proj_coa.w, h->proj_coa.kpad, nullptr, h->c2, d, Beff, d, d, 0, s));
         p = GemmParams{h->emb_pose, d, h->proj_pose.w, h->proj_pose.kpad, nullptr, h->addend, d, h->c2, d, h->xseq, d, Beff * T, d, d, T, B};
         if (gemm(A_ROWS, B_WEIGHT, OUT_ROWS, EPI_RES_VEC, p, s)) return -1;
         HIPCHK(launch_local_attention(h->xseq, h->rope_cos, h->rope_sin, h->xa, nullptr, Beff, T, d, h->cfg.cl_head,
@@ -548,14 +561,20 @@ static int forward_core_f16(gdx_model* h, const float* x, const float* temb, int
     float* const tap32 = h->keep_taps ? h->xa : nullptr;              // fp32 copies only for the parity taps
     HIPCHK(launch_transpose_in_f16(x, h->xt16, Beff, B, J, T, Jp, s));
     if (h->cfg.arch == GDX_ARCH_MDM_OLD) {
-        HIPCHK(launch_token0(temb, tstride, seed_emb, h->pe, h->xa, h->xa16, nullptr, Beff, B, S, d, s));
+        HIPCHK(launch_token0(temb, tstride, seed_emb, h->pe, h->xa, h->xa16, nullptr, nullptr, nullptr, nullptr, Beff, B, S, d, s));
         if (gemm_f16(h->xt16, Jp, h->in_x, nullptr, h->addend, d, nullptr, 0, tap32, d, h->xa16, d, Beff * T, d, T, 1, 0, s))
             return -1;
     } else {
-        HIPCHK(launch_token0(temb, tstride, seed_emb, nullptr, h->xa, h->xa16, h->coa, Beff, B, S, d, s));
+        // inside a sampling loop the coarse slice of project_to_lat is table row + per-sample vector (see gdx_sample_loop)
+        const bool hoist = h->c2t_valid && tstride == 0 && temb >= h->temb_table &&
+                           temb < h->temb_table + (size_t)h->temb_table_rows * d;
+        const float* c2t_row = hoist ? h->c2t_table + (temb - h->temb_table) : nullptr;
+        const float* c2s = mode == GDX_UNCOND ? h->c2_seed + (size_t)B * d : h->c2_seed;
+        HIPCHK(launch_token0(temb, tstride, seed_emb, nullptr, h->xa, h->xa16, h->coa, c2t_row, c2s, hoist ? h->c2 : nullptr,
+                             Beff, B, S, d, s));
         if (gemm_f16(h->xt16, Jp, h->in_x, h->in_x.bias, nullptr, 0, nullptr, 0, nullptr, 0, h->emb16, d, Beff * T, d, T, 0, 0, s))
             return -1;
-        HIPCHK(launch_small_linear(h->coa, d, h->proj_coa.w, h->proj_coa.kpad, nullptr, h->c2, d, Beff, d, d, 0, s));
+        if (!hoist) HIPCHK(launch_small_linear(h->coa, d, h->proj_coa.w, h->proj_coa.kpad, nullptr, h->c2, d, Beff, d, d, 0, s));
         if (local_attention_f16_supported(d, h->cfg.cl_head, h->cfg.window)) {
             if (gemm_f16(h->emb16, d, h->proj_pose, nullptr, h->addend, d, h->c2, d, nullptr, 0, h->xseq16, d, Beff * T, d, T, 0, 0, s))
                 return -1;
@@ -608,10 +627,15 @@ static int check_ready(gdx_model* h, const char* who) {
 
 // timestep embedding rows for idx[M] (model/mdm.py:296-310): pe gather -> Linear -> SiLU -> Linear
 static int time_embed(gdx_model* h, const int64_t* idx, int M, float* gathered, float* hidden, float* out,
-                      hipStream_t s) {
+                      bool table, hipStream_t s) {
     const int d = h->d;
     HIPCHK(launch_gather_rows(h->pe, idx, gathered, M, d, h->pe_rows, s));
     HIPCHK(launch_small_linear(gathered, d, h->time0.w, h->time0.kpad, h->time0.bias, hidden, d, M, d, d, 1, s));
+    if (table && M >= 64) {   // whole-loop tables only (per-sample embeddings keep one batch-size-independent kernel):
+                              // the persistent GEMM; the caller pads `hidden` / `out` by >= 128 rows
+        GemmParams p{hidden, d, h->time2.w, h->time2.kpad, h->time2.bias, nullptr, 0, nullptr, 0, out, d, M, d, d, 1, 1};
+        return gemm(A_ROWS, B_WEIGHT, OUT_ROWS, EPI_BIAS, p, s);
+    }
     HIPCHK(launch_small_linear(hidden, d, h->time2.w, h->time2.kpad, h->time2.bias, out, d, M, d, d, 0, s));
     return 0;
 }
@@ -623,7 +647,7 @@ extern "C" int gdx_forward(gdx_handle_t h, const float* x, const int64_t* timest
     if (mode < GDX_COND || mode > GDX_CFG) return fail("gdx_forward: bad mode");
     if (mode == GDX_CFG && !scale) return fail("gdx_forward: GDX_CFG needs scale");
     hipStream_t s = (hipStream_t)stream;
-    if (time_embed(h, timesteps, h->B, h->temb_in, h->temb_h, h->temb, s)) return -1;
+    if (time_embed(h, timesteps, h->B, h->temb_in, h->temb_h, h->temb, false, s)) return -1;
     if (mode != GDX_CFG) return forward_core(h, x, h->temb, h->d, mode, out, s);
     if (forward_core(h, x, h->temb, h->d, mode, h->x0, s)) return -1;
     const int64_t per = (int64_t)h->J * h->T;
@@ -645,7 +669,11 @@ extern "C" int gdx_sample_loop(gdx_handle_t h, const gdx_loop_args_t* a, void* s
     // gaussian_diffusion.py:712), through the respacing map (respace.py:124-129)
     if (h->temb_table_rows < a->num_steps) {
         float* t3 = nullptr;
-        if (dev_alloc(h->ws_allocs, (void**)&t3, sizeof(float) * 3 * (size_t)a->num_steps * d)) return -1;
+        // + 256 / + 128 rows: the table linears run on the persistent GEMM, which reads / stores whole tiles
+        if (dev_alloc(h->ws_allocs, (void**)&t3, sizeof(float) * (3 * (size_t)a->num_steps + 256) * d)) return -1;
+        HIPCHK(hipMemsetAsync(t3, 0, sizeof(float) * (3 * (size_t)a->num_steps + 256) * d, s));
+        if (h->cfg.arch == GDX_ARCH_MDM && dev_alloc(h->ws_allocs, (void**)&h->c2t_table, sizeof(float) * ((size_t)a->num_steps + 128) * d))
+            return -1;
         if (dev_alloc(h->ws_allocs, (void**)&h->tmap_dev, sizeof(int64_t) * a->num_steps)) return -1;
         h->temb_table = t3;
         h->temb_table_rows = a->num_steps;
@@ -654,7 +682,17 @@ extern "C" int gdx_sample_loop(gdx_handle_t h, const gdx_loop_args_t* a, void* s
     float* table = h->temb_table;
     float* scratch0 = table + (size_t)h->temb_table_rows * d;
     float* scratch1 = scratch0 + (size_t)h->temb_table_rows * d;
-    if (time_embed(h, h->tmap_dev, a->num_steps, scratch0, scratch1, table, s)) return -1;
+    if (time_embed(h, h->tmap_dev, a->num_steps, scratch0, scratch1, table, true, s)) return -1;
+    if (h->cfg.arch == GDX_ARCH_MDM) {
+        // timestep half of the coarse slice of project_to_lat for every kept step, once per loop
+        if (a->num_steps >= 64) {
+            GemmParams p{table, d, h->proj_coa.w, h->proj_coa.kpad, nullptr, nullptr, 0, nullptr, 0, h->c2t_table, d, a->num_steps, d, d, 1, 1};
+            if (gemm(A_ROWS, B_WEIGHT, OUT_ROWS, EPI_BIAS, p, s)) return -1;
+        } else {
+            HIPCHK(launch_small_linear(table, d, h->proj_coa.w, h->proj_coa.kpad, nullptr, h->c2t_table, d, a->num_steps, d, d, 0, s));
+        }
+        h->c2t_valid = true;
+    }
 
     const int64_t per = (int64_t)h->J * h->T;
     int dump_i = 0;

@@ -91,8 +91,11 @@ hipError_t launch_mfcc_project(const float* mfcc, const float* W, int ldw, const
                                float* out, int B, int Bmod, int C, int T, int d, int rps, int off, hipStream_t s);
 // token 0 of the encoder input: enc[b*S*d + n] = temb[(b%Bmod)*tstride + n] + seed[b*d + n] (+ pe0[n]);
 // also writes coa[b*d+n] (same value without pe0) when coa != nullptr.
+// c2 != nullptr: c2[b*d+n] = c2t_row[n] + c2_seed[b*d+n]  (V2: the coarse slice of project_to_lat, hoisted per loop /
+// per conditioning instead of a [B,d] x [d,d] linear per step)
 hipError_t launch_token0(const float* temb, int tstride, const float* seed_emb, const float* pe0,
-                         float* enc, _Float16* enc16, float* coa, int B, int Bmod, int S, int d, hipStream_t s);
+                         float* enc, _Float16* enc16, float* coa, const float* c2t_row, const float* c2_seed, float* c2,
+                         int B, int Bmod, int S, int d, hipStream_t s);
 // V2 front end: RoPE -> causal local attention (window, look back one window) -> RoPE at pos+1,
 // written into enc[b][t+1][:].   xseq [B*T][d];  cos/sin tables [>=T+1][e/2], e = d/heads.
 hipError_t launch_local_attention(const float* xseq, const float* cosT, const float* sinT, float* enc,
