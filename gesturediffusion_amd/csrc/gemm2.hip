@@ -58,6 +58,17 @@ __device__ __forceinline__ float gelu_fast(float x) { return x * 0.5f * (1.0f + 
 template <int N>
 __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
+template <int R, int NRD, int NMM>
+__device__ __forceinline__ void g4_sched_interleave() {
+    if constexpr (R < NRD) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);        // MFMA
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);        // DS read
+        g4_sched_interleave<R + 1, NRD, NMM>();
+    } else if constexpr (NMM > NRD) {
+        __builtin_amdgcn_sched_group_barrier(0x008, NMM - NRD, 0);
+    }
+}
+
 template <int MB, int NBW, int BK, int NST>
 __global__ __launch_bounds__(512, 1) void gemm4_kernel(const GemmParams p, const int epi, const int omode, const int ntn,
                                                        const int ntiles, unsigned long long* dbg) {
@@ -191,18 +202,26 @@ __global__ __launch_bounds__(512, 1) void gemm4_kernel(const GemmParams p, const
 
     int ks = 0, stage = 0, tile_i = 0;
     rd(fa0, fb0, 0, 0);
+    // scheduling recipe for one fragment group: its MB + NBW reads (of the NEXT group) go out one per MFMA right at the
+    // start of this group's 4 * MB * NBW MFMAs; left to itself the compiler sinks them to the end of the MFMA block and
+    // the next group then waits out the LDS latency (~120 cycles per group); A/B in one session: 0-4 % faster
+    auto interleave = [&]() { g4_sched_interleave<0, MB + NBW, 4 * MB * NBW>(); };
     for (int g = 0; g < total; ++g) {
         const int nstage = stage == NST - 1 ? 0 : stage + 1;
         rd(fa1, fb1, stage, 1);
         mm(fa0, fb0);
+        interleave();
         if (KK == 4) {
             rd(fa0, fb0, stage, 2);
             mm(fa1, fb1);
+            interleave();
             rd(fa1, fb1, stage, 3);
             mm(fa0, fb0);
+            interleave();
         }
-        if (g + 1 < total) rd(fa0, fb0, nstage, 0);          // next slab's first group: landed before the last barrier
-        mm(fa1, fb1);
+        rd(fa0, fb0, nstage, 0);                              // next slab's first group: landed before the last barrier
+        mm(fa1, fb1);                                         // (past the last slab: a stale stage, never used)
+        interleave();
         if (++ks == nk) {
             ks = 0;
             // ---- epilogue straight from the accumulators (col = lane&15, row = 4*(lane>>4) + reg); whole tiles
