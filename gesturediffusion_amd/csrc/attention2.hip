@@ -154,14 +154,27 @@ __global__ __launch_bounds__(512, 1) void attention2_kernel(const float* __restr
             f32x4 s[QB];
 #pragma unroll
             for (int qi = 0; qi < QB; ++qi) s[qi] = f32x4{0.f, 0.f, 0.f, 0.f};
+            // K fragments through a register ring two reads ahead of their MFMAs: a read issued right in front of
+            // the 8 MFMAs it feeds left the matrix pipe idle for most of the LDS latency, once per fragment
+            constexpr int PD = 2;
+            auto kread = [&](int kk) { return *reinterpret_cast<const f32x4*>(&Ks[(kb * 16 + l15) * KS + 16 * kk + 4 * lq]); };
+            f32x4 kring[PD + 1];
 #pragma unroll
+            for (int kk = 0; kk < PD; ++kk) kring[kk] = kread(kk);
+            __builtin_amdgcn_sched_group_barrier(0x100, PD, 0);       // pin the order: the scheduler otherwise moves
+#pragma unroll                                                       // every read back in front of its own MFMAs
             for (int kk = 0; kk < NKK; ++kk) {
-                const f32x4 kf = *reinterpret_cast<const f32x4*>(&Ks[(kb * 16 + l15) * KS + 16 * kk + 4 * lq]);
+                if (kk + PD < NKK) {
+                    kring[(kk + PD) % (PD + 1)] = kread(kk + PD);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                }
+                const f32x4 kf = kring[kk % (PD + 1)];
 #pragma unroll
                 for (int c = 0; c < 4; ++c)
 #pragma unroll
                     for (int qi = 0; qi < NQ; ++qi)
                         s[qi] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[c], qf[qi][kk][c], s[qi], 0, 0, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 4 * NQ, 0);
             }
             // ---- online softmax per query (lane column l15; keys 4lq+e in this lane).  The reference value m_run
             //      only has to bound the scores from above within exp range, not equal their max: it is raised (with
@@ -196,17 +209,29 @@ __global__ __launch_bounds__(512, 1) void attention2_kernel(const float* __restr
                 l_run[qi] += psum;
             }
             // ---- O^T += V^T P^T: register e of the probability tile is the B operand of k-step e ----
+            constexpr int NV = 4 * NG;
+            auto vread = [&](int r) {
+                return *reinterpret_cast<const f32x4*>(&Vs[(kb * 16 + 4 * lq + r / NG) * HD + 64 * (r % NG) + 4 * l15]);
+            };
+            f32x4 vring[PD + 1];
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
+            for (int r = 0; r < PD; ++r) vring[r] = vread(r);
+            __builtin_amdgcn_sched_group_barrier(0x100, PD, 1);
 #pragma unroll
-                for (int g = 0; g < NG; ++g) {
-                    const f32x4 vf = *reinterpret_cast<const f32x4*>(&Vs[(kb * 16 + 4 * lq + e) * HD + 64 * g + 4 * l15]);
-#pragma unroll
-                    for (int c = 0; c < 4; ++c)
-#pragma unroll
-                        for (int qi = 0; qi < NQ; ++qi)
-                            o[qi][g][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(vf[c], s[qi][e], o[qi][g][c], 0, 0, 0);
+            for (int r = 0; r < NV; ++r) {
+                if (r + PD < NV) {
+                    vring[(r + PD) % (PD + 1)] = vread(r + PD);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 1);
                 }
+                const f32x4 vf = vring[r % (PD + 1)];
+                const int e = r / NG, g = r % NG;
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+#pragma unroll
+                    for (int qi = 0; qi < NQ; ++qi)
+                        o[qi][g][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(vf[c], s[qi][e], o[qi][g][c], 0, 0, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 4 * NQ, 1);
+            }
         }
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // tile consumed; the loaders waited for the next one
         stage = stage == NST - 1 ? 0 : stage + 1;
