@@ -539,3 +539,31 @@ def test_plms_loops_vs_reference_golden(arch, name, order):
         df.plms_sample_loop(model, tuple(x_T.shape), noise=x_T.clone(), clip_denoised=False, model_kwargs={"y": y}, order=1)
     with pytest.raises(ValueError):
         df.plms_sample_loop(model, tuple(x_T.shape), noise=x_T.clone(), clip_denoised=False, model_kwargs={"y": y}, order=5)
+
+
+def test_fp16_mode_switch_and_reshape_on_one_model():
+    """The compute mode is a property of the engine, not of the weights: one model object switches fp32 -> fp16 -> fp32
+    (engine re-created, weights re-packed) and is re-prepared for another (B, T) in between; the fp32 results before and
+    after are identical, the fp16 ones within the fp16 tolerance of them."""
+    from gesturediffusion_amd.utils.init import init_state_dict, synthetic_inputs
+    cfg = dict(arch="mdm_old", njoints=53, nfeats=1, latent_dim=256, ff_size=512, num_layers=2, num_heads=4, seed_poses=10)
+    m = build_model("mdm_old", cfg, init_state_dict(cfg, seed=3, perturb=True))
+    d = dev()
+
+    def run(B, T):
+        x, seedp, mfcc = synthetic_inputs(cfg, B, T, seed=B + T)
+        t = (torch.arange(B) * 37 + 5) % 1000
+        return m(x.to(d), t.to(d), {"seed": seedp.to(d), "mfcc": mfcc.to(d)})
+    a32 = run(3, 50)
+    m.compute_dtype = "fp16"
+    a16 = run(3, 50)
+    b16 = run(5, 33)
+    m.compute_dtype = "fp32"
+    b32 = run(5, 33)
+    again = run(3, 50)
+    assert torch.equal(a32, again)
+    assert rel_err(a16.cpu(), a32.cpu()) < F16_TOL and rel_err(b16.cpu(), b32.cpu()) < F16_TOL
+    assert not torch.equal(a16, a32)
+    with pytest.raises(ValueError):
+        m.compute_dtype = "int8"
+        run(3, 50)
