@@ -249,8 +249,14 @@ __global__ __launch_bounds__(512, 1) void gemm4_kernel(const GemmParams p, const
                     }
                 }
             } else {
-                // general epilogue (boundary linears): token-row map, hoisted per-token term R, per-sample vector V
+                // general epilogue (boundary linears): token-row map, hoisted per-token term R, per-sample vector V.
+                // Two passes: every R / V load of the tile first, then the adds and stores.  In one pass the compiler
+                // cannot move a load of R above the preceding store to C (it cannot prove they do not alias), so the
+                // tile paid one L2 round trip per element: ~11 us per tile, 92 us for the input linear (MFMA
+                // utilisation 0.29, profiles/r01e_pmc_mfma_util_fp32_*).
                 const bool need_b = rowmap || p.V != nullptr;
+                f32x4 add[MB][NBW];
+                long rows[MB][4];
 #pragma unroll
                 for (int i = 0; i < MB; ++i) {
                     // sample index of this lane's 4 rows: one division per 16-row block, then at most one sample
@@ -266,22 +272,36 @@ __global__ __launch_bounds__(512, 1) void gemm4_kernel(const GemmParams p, const
                         }
                     }
 #pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int m = m0 + i * 16 + 4 * lq + e;
+                        rows[i][e] = rowmap ? (long)m + bs[e] + 1 : (long)m;
+                    }
+#pragma unroll
+                    for (int j = 0; j < NBW; ++j) {
+                        const int n = n0 + wave * WN + j * 16 + l15;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            float a = 0.0f;
+                            if (p.R) a = p.R[rows[i][e] * p.ldr + n];
+                            if (p.V) a += p.V[(long)bs[e] * p.ldv + n];     // (acc + bias) + (R + V): covered by the fixtures
+                            add[i][j][e] = a;
+                        }
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < MB; ++i)
+#pragma unroll
                     for (int j = 0; j < NBW; ++j) {
                         const int n = n0 + wave * WN + j * 16 + l15;
                         const float bv = bias_lds[n];
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
-                            const int m = m0 + i * 16 + 4 * lq + e;
-                            const long row_out = rowmap ? (long)m + bs[e] + 1 : (long)m;
-                            float v = acc[i][j][e] + bv;
-                            if (p.R) v += p.R[row_out * p.ldr + n];
-                            if (p.V) v += p.V[(long)bs[e] * p.ldv + n];
+                            float v = (acc[i][j][e] + bv) + add[i][j][e];
                             if (epi == EPI_GELU) v = gelu_fast(v);
-                            p.C[row_out * p.ldc + n] = v;
+                            p.C[rows[i][e] * p.ldc + n] = v;
                         }
                         acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
                     }
-                }
             }
         }
         // the loaders have waited for slab g+2 before this barrier; step g+1 prefetches from it

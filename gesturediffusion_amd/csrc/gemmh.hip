@@ -65,9 +65,14 @@ __device__ __forceinline__ f32x2 gelu2(f32x2 x) {
 // Epilogue of one wave: its MB x NBW accumulator blocks (swapped MFMA: lane & 15 = row inside a 16-row block, registers
 // = columns q*4*NBW + j*4 + e) -> bias / R / V / GELU -> fp32 and / or fp16 stores.  (m0, nw0) = first row / column of
 // the wave's sub-tile.  Clears the accumulators.
+// The output / residual pointers are restrict-qualified PARAMETERS so that, after inlining, the compiler may hoist the
+// R / V loads of later rows above the stores of earlier ones (they never alias: different workspace buffers); through
+// the by-value parameter struct it had to serialise load -> store -> load, one L2 round trip per 16-row block.
 template <int MB, int NBW>
-__device__ __forceinline__ void wave_epilogue(const GemmHParams& p, f32x4 (&acc)[MB][NBW], const float* bias_lds, int m0,
-                                              int nw0, int l15, int lq) {
+__device__ __forceinline__ void wave_epilogue_impl(const GemmHParams& p, f32x4 (&acc)[MB][NBW], const float* bias_lds,
+                                                   int m0, int nw0, int l15, int lq, const float* __restrict__ pR,
+                                                   const float* __restrict__ pV, float* __restrict__ pC32,
+                                                   _Float16* __restrict__ pC16) {
     const int nb = nw0 + lq * (4 * NBW);
     f32x4 bv[NBW];
 #pragma unroll
@@ -84,17 +89,17 @@ __device__ __forceinline__ void wave_epilogue(const GemmHParams& p, f32x4 (&acc)
         if (m < p.M) {
             long ro = m;
             int bs = 0;
-            if (p.rowmap || p.V) {
+            if (p.rowmap || pV) {
                 bs = m / p.T;
                 if (p.rowmap) ro = (long)m + bs + 1;
             }
-            if (p.R) {
+            if (pR) {
 #pragma unroll
-                for (int j = 0; j < NBW; ++j) v[j] += *reinterpret_cast<const f32x4*>(&p.R[ro * p.ldr + nb + j * 4]);
+                for (int j = 0; j < NBW; ++j) v[j] += *reinterpret_cast<const f32x4*>(&pR[ro * p.ldr + nb + j * 4]);
             }
-            if (p.V) {
+            if (pV) {
 #pragma unroll
-                for (int j = 0; j < NBW; ++j) v[j] += *reinterpret_cast<const f32x4*>(&p.V[(long)bs * p.ldv + nb + j * 4]);
+                for (int j = 0; j < NBW; ++j) v[j] += *reinterpret_cast<const f32x4*>(&pV[(long)bs * p.ldv + nb + j * 4]);
             }
             if (p.gelu) {
 #pragma unroll
@@ -103,12 +108,12 @@ __device__ __forceinline__ void wave_epilogue(const GemmHParams& p, f32x4 (&acc)
                     v[j] = f32x4{lo.x, lo.y, hi.x, hi.y};
                 }
             }
-            if (p.C32) {
+            if (pC32) {
 #pragma unroll
-                for (int j = 0; j < NBW; ++j) *reinterpret_cast<f32x4*>(&p.C32[ro * p.ldc32 + nb + j * 4]) = v[j];
+                for (int j = 0; j < NBW; ++j) *reinterpret_cast<f32x4*>(&pC32[ro * p.ldc32 + nb + j * 4]) = v[j];
             }
-            if (p.C16) {
-                _Float16* cp = p.C16 + ro * p.ldc16 + nb;
+            if (pC16) {
+                _Float16* cp = pC16 + ro * p.ldc16 + nb;
                 if constexpr (NBW == 1) {
                     *reinterpret_cast<f16x4*>(cp) =
                         f16x4{(_Float16)v[0][0], (_Float16)v[0][1], (_Float16)v[0][2], (_Float16)v[0][3]};
@@ -122,6 +127,12 @@ __device__ __forceinline__ void wave_epilogue(const GemmHParams& p, f32x4 (&acc)
             }
         }
     }
+}
+
+template <int MB, int NBW>
+__device__ __forceinline__ void wave_epilogue(const GemmHParams& p, f32x4 (&acc)[MB][NBW], const float* bias_lds, int m0,
+                                              int nw0, int l15, int lq) {
+    wave_epilogue_impl<MB, NBW>(p, acc, bias_lds, m0, nw0, l15, lq, p.R, p.V, p.C32, p.C16);
 }
 
 // scheduling recipe for one K step: one ds_read after every PER MFMAs over the first ~2/3 of the NMM MFMAs, the
