@@ -175,6 +175,25 @@ __global__ void plms_kernel(int kind, const float* __restrict__ coef, const int6
     out[i] = __fadd_rn(__fmul_rn(mean, nz), __fmul_rn(x0[i], __fsub_rn(1.0f, nz)));
 }
 
+// De-normalisation + position / rotation split of a generated chunk (reference sample/generate.py:132-146 with
+// data_loaders/gesture/data/dataset.py:118-119): feature 6j+c is rotation component c of joint j, 6j+3+c its position.
+//   pos[b][j][c][t] = x[b][6j+3+c][t] * std[6j+3+c] + mean[6j+3+c],  rot[b][j][c][t] likewise with feature 6j+c.
+// The reference multiplies the fp32 sample by fp64 statistics and rounds once at the end (.float()); so does this.
+__global__ void postprocess_kernel(const float* __restrict__ x, const double* __restrict__ mean,
+                                   const double* __restrict__ stdv, float* __restrict__ pos, float* __restrict__ rot,
+                                   int nj, int T, long total) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int t = i % T;
+    const long r = i / T;                  // b * 6nj + f
+    const int f = r % (6 * nj);
+    const long b = r / (6 * nj);
+    const int j = f / 6, c = f % 6;
+    const float v = (float)__dadd_rn(__dmul_rn((double)x[i], stdv[f]), mean[f]);
+    float* dst = c < 3 ? rot : pos;
+    dst[((b * nj + j) * 3 + (c % 3)) * T + t] = v;
+}
+
 __global__ void randn_kernel(float* __restrict__ out, int batch, long per_sample, long groups, uint64_t seed,
                              uint64_t sample_offset, uint32_t step) {
     const long gid = (long)blockIdx.x * 256 + threadIdx.x;
@@ -258,6 +277,16 @@ extern "C" int gdx_plms_update(const gdx_plms_args_t* a, void* stream) {
                        a->step_index, a->x, a->pred_xstart, a->eps[0], a->eps[1], a->eps[2], a->eps[3], a->out,
                        (long)a->per_sample, total);
     return hipGetLastError() == hipSuccess ? 0 : gdx_set_error_("gdx_plms_update: launch failed");
+}
+
+extern "C" int gdx_postprocess(const float* x, const double* mean, const double* stdv, float* pos, float* rot,
+                               int32_t batch, int32_t n_joints, int32_t frames, void* stream) {
+    if (!x || !mean || !stdv || !pos || !rot) return gdx_set_error_("gdx_postprocess: null argument");
+    const long total = (long)batch * n_joints * 6 * frames;
+    if (total <= 0) return 0;
+    hipLaunchKernelGGL(gdx::postprocess_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, x, mean,
+                       stdv, pos, rot, n_joints, frames, total);
+    return hipGetLastError() == hipSuccess ? 0 : gdx_set_error_("gdx_postprocess: launch failed");
 }
 
 extern "C" int gdx_randn(float* out, int32_t batch, int64_t per_sample, uint64_t philox_seed, uint64_t sample_offset,

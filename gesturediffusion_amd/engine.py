@@ -190,6 +190,24 @@ def plms_update(kind, coef, t, x, pred_xstart, eps=(), out=None):
     return out
 
 
+def postprocess(sample, mean, std):
+    """inv_transform + position / rotation split of a generated chunk on the device (reference
+    sample/generate.py:132-146): sample [B, 6*nj, 1, T] -> (positions, rotations), each [B, nj, 3, T]."""
+    lib = _lib.load()
+    x = f32c(sample, "sample")
+    B, J, F, T = x.shape
+    if F != 1 or J % 6:
+        raise ValueError(f"expected [B, 6*n_joints, 1, T], got {tuple(x.shape)}")
+    mean = torch.as_tensor(mean, dtype=torch.float64, device=x.device).contiguous()
+    std = torch.as_tensor(std, dtype=torch.float64, device=x.device).contiguous()
+    if mean.numel() != J or std.numel() != J:
+        raise ValueError("mean / std must have one entry per feature")
+    pos = torch.empty(B, J // 6, 3, T, device=x.device, dtype=torch.float32)
+    rot = torch.empty_like(pos)
+    _lib.check(lib.gdx_postprocess(_ptr(x), _ptr(mean), _ptr(std), _ptr(pos), _ptr(rot), B, J // 6, T, _stream(x.device)), lib)
+    return pos, rot
+
+
 def q_sample(x_start, noise, coef, idx):
     lib = _lib.load()
     out = torch.empty_like(x_start)

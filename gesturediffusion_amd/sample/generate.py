@@ -3,9 +3,12 @@
 Keeps the reference CLI's flags and flow (`sample/generate.py:23-183`): args.json override,
 fixseed, model + diffusion factory, checkpoint load, optional classifier-free-guidance wrapper,
 then `chunks` autoregressive chunks, each a full sampling loop whose seed poses are the last
-`seed_poses` frames of the previous chunk (`:104-107`).  Dataset loading, BVH/MP4 writing and
-SMPL post-processing (GENEA data, bvhsdk, ffmpeg) are out of scope; with `--synthetic` the
-conditioning is N(0,1) and the script writes `results.npy` with the normalised poses.
+`seed_poses` frames of the previous chunk (`:104-107`).  Dataset loading and BVH/MP4 writing
+(GENEA data, bvhsdk, ffmpeg) are out of scope; with `--synthetic` the conditioning is N(0,1).  The chunk tail of the
+reference (`:132-146`: inv_transform with the dataset statistics, position / rotation split; rot2xyz is the identity for
+pose_rep 'xyz') runs on the device (`gdx_postprocess`) whenever the feature count is 6 per joint (GENEA: 83 x 6 = 498),
+with synthetic statistics; `results.npy` then holds `motion` [B, n_joints, 3, T*chunks] and `motion_rot` like the
+reference's, otherwise the normalised poses [B, J, 1, T*chunks].
 
 Multi-GPU: launch with `python -m torch.distributed.run --nproc-per-node N ...`; the batch is
 sharded across ranks and gathered once at the end of every chunk (RCCL over xGMI).
@@ -15,6 +18,7 @@ import os
 import numpy as np
 import torch
 
+from .. import engine as E
 from ..model.cfg_sampler import ClassifierFreeSampleModel
 from ..utils import dist_util
 from ..utils.fixseed import fixseed
@@ -55,7 +59,11 @@ def main(argv=None):
     J, T = model.njoints, args.num_frames
     g = torch.Generator().manual_seed(args.seed)
     seed_all = torch.randn(num_samples, J, 1, args.seed_poses, generator=g)
-    out_chunks = []
+    out_chunks, rot_chunks = [], []
+    split6 = J % 6 == 0                                   # GENEA layout: 3 rotation + 3 position features per joint
+    if split6:
+        stat_rng = np.random.default_rng(args.seed)       # stand-in for the dataset's Mean.npy / Std.npy (fp64)
+        mean, std = stat_rng.normal(size=J), stat_rng.uniform(0.5, 2.0, size=J)
     sample_fn = diffusion.p_sample_loop if args.sampler == "p" else diffusion.ddim_sample_loop
     sample_out = None
     for chunk in range(args.chunks):
@@ -74,13 +82,20 @@ def main(argv=None):
         sample_out = sample_fn(model, (nb, J, 1, T), **kw)
         full = dist_util.gather_samples(sample_out, num_samples)
         if rank == 0:
-            out_chunks.append(full.cpu().numpy())
+            if split6:
+                pos, rot = E.postprocess(full, mean, std)   # inv_transform + index split on the device
+                out_chunks.append(pos.cpu().numpy())
+                rot_chunks.append(rot.cpu().numpy())
+            else:
+                out_chunks.append(full.cpu().numpy())
     if rank == 0:
         out_path = args.output_dir or os.path.join(os.getcwd(), f"samples_synthetic_seed{args.seed}")
         os.makedirs(out_path, exist_ok=True)
         motion = np.concatenate(out_chunks, axis=3)
-        np.save(os.path.join(out_path, "results.npy"), {"motion": motion, "num_samples": num_samples,
-                                                         "num_chunks": args.chunks}, allow_pickle=True)
+        res = {"motion": motion, "num_samples": num_samples, "num_chunks": args.chunks}
+        if split6:
+            res["motion_rot"] = np.concatenate(rot_chunks, axis=3)
+        np.save(os.path.join(out_path, "results.npy"), res, allow_pickle=True)
         print(f"saved results to [{os.path.join(out_path, 'results.npy')}] motion {motion.shape}")
     return 0
 

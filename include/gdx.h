@@ -167,6 +167,14 @@ int gdx_q_sample(const float* x_start, const float* noise, const float* coef, in
 int gdx_randn(float* out, int32_t batch, int64_t per_sample, uint64_t philox_seed,
               uint64_t sample_offset, uint32_t rng_step, void* stream);
 
+/* ---- chunk post-processing ----------------------------------------------- */
+/* replaces the CPU tail of the reference's chunk loop (sample/generate.py:132-146): inv_transform
+ * (data * std + mean with the dataset's fp64 statistics, data_loaders/gesture/data/dataset.py:118-119, rounded to
+ * fp32 once) and the split of the 6-per-joint feature vector into positions (6j+3..5) and rotations (6j..2).
+ * x [B, 6*n_joints, 1, T] fp32, mean / std [6*n_joints] fp64 (device), pos / rot [B, n_joints, 3, T] fp32. */
+int gdx_postprocess(const float* x, const double* mean, const double* std, float* pos, float* rot,
+                    int32_t batch, int32_t n_joints, int32_t frames, void* stream);
+
 /* ---- whole loop ------------------------------------------------------------------------ */
 /* replaces p_sample_loop / ddim_sample_loop (gaussian_diffusion.py:598-661, 879-926) in the
  * configured mode (START_X, FIXED_SMALL, clip_denoised=False): iterates index = first_index

@@ -150,3 +150,21 @@ def plms_loop(model_fn, tab, tmap, shape, x_T, y, order=2, skip_timesteps=0, ini
     for i in indices:
         img, _, old = plms_step(x0_fn, tab, img, torch.tensor([i] * B), order, old)
     return img
+
+
+# ---------------------------------------------------------------------------------------------
+def postprocess_chunk(sample_out, mean, std):
+    """Tail of the reference's chunk loop, sample/generate.py:132-146 (rot2xyz with pose_rep 'xyz' is the identity):
+    inv_transform on [B, 1, T, J] (torch fp32 * numpy fp64 statistics -> fp64, then .float()), then the position /
+    rotation index split and the permute to [B, n_joints, 3, T]."""
+    import numpy as np
+    n_joints = sample_out.shape[1] // 6
+    sample = (sample_out.cpu().permute(0, 2, 3, 1) * torch.from_numpy(np.asarray(std)) + torch.from_numpy(np.asarray(mean))).float()
+    idx_positions = np.asarray([[i * 6 + 3, i * 6 + 4, i * 6 + 5] for i in range(n_joints)]).flatten()
+    idx_rotations = np.asarray([[i * 6, i * 6 + 1, i * 6 + 2] for i in range(n_joints)]).flatten()
+    pos, rot = sample[..., idx_positions], sample[..., idx_rotations]
+    pos = pos.view(pos.shape[:-1] + (-1, 3))
+    pos = pos.view(-1, *pos.shape[2:]).permute(0, 2, 3, 1)
+    rot = rot.view(rot.shape[:-1] + (-1, 3))
+    rot = rot.view(-1, *rot.shape[2:]).permute(0, 2, 3, 1)
+    return pos, rot

@@ -367,6 +367,7 @@ def test_error_behaviour_matches_reference(golden_dir):
 
 @pytest.mark.parametrize("extra", [["--arch_version", "mdm_old", "--num_frames", "23", "--guidance_param", "1"],
                                    ["--arch_version", "mdm", "--num_frames", "20", "--compute_dtype", "fp16"],
+                                   ["--arch_version", "mdm", "--num_frames", "20", "--synthetic_njoints", "48"],
                                    ["--arch_version", "mdm", "--num_frames", "20", "--rng", "philox"],
                                    ["--arch_version", "mdm", "--num_frames", "20", "--sampler", "ddim", "--timestep_respacing", "ddim10"]])
 def test_generate_cli_synthetic(tmp_path, extra):
@@ -381,8 +382,12 @@ def test_generate_cli_synthetic(tmp_path, extra):
     assert generate.main(base + extra) == 0
     res = np.load(out / "results.npy", allow_pickle=True).item()      # written by this test a moment ago
     frames = int(extra[extra.index("--num_frames") + 1])
-    assert res["motion"].shape == (3, 37, 1, 2 * frames) and np.isfinite(res["motion"]).all()
-    assert np.abs(res["motion"]).max() > 0
+    if "--synthetic_njoints" in extra:          # 6 features per joint: de-normalised positions + rotations (gdx_postprocess)
+        assert res["motion"].shape == (3, 8, 3, 2 * frames) and res["motion_rot"].shape == (3, 8, 3, 2 * frames)
+        assert np.isfinite(res["motion_rot"]).all()
+    else:
+        assert res["motion"].shape == (3, 37, 1, 2 * frames)
+    assert np.isfinite(res["motion"]).all() and np.abs(res["motion"]).max() > 0
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -567,3 +572,18 @@ def test_fp16_mode_switch_and_reshape_on_one_model():
     with pytest.raises(ValueError):
         m.compute_dtype = "int8"
         run(3, 50)
+
+
+def test_postprocess_chunk_bit_exact():
+    """gdx_postprocess (inv_transform + position / rotation split, reference sample/generate.py:132-146) against the
+    CPU restatement: identical bits (fp64 statistics, one rounding)."""
+    from gesturediffusion_amd import engine as E
+    from oracle import sampler as osamp
+    g = torch.Generator().manual_seed(4)
+    B, nj, T = 3, 83, 120                                   # GENEA: 83 joints x 6 = 498 features, 120-frame chunks
+    x = torch.randn(B, nj * 6, 1, T, generator=g)
+    rng = np.random.default_rng(0)
+    mean, std = rng.normal(size=nj * 6), rng.uniform(0.1, 3.0, size=nj * 6)
+    pos, rot = E.postprocess(x.to(dev()), mean, std)
+    wp, wr = osamp.postprocess_chunk(x, mean, std)
+    assert pos.shape == (B, nj, 3, T) and torch.equal(pos.cpu(), wp.contiguous()) and torch.equal(rot.cpu(), wr.contiguous())
