@@ -130,10 +130,11 @@ __global__ __launch_bounds__(256) void update_kernel(const UpdateDev a) {
 }
 
 __global__ void q_sample_kernel(const float* __restrict__ xs, const float* __restrict__ nz, const float* coef,
-                                int idx, long n, float* __restrict__ out) {
+                                int idx, const int64_t* __restrict__ t, long per_sample, long n, float* __restrict__ out) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const float a = coef[idx * 8 + 5], b = coef[idx * 8 + 6];
+    const long row = t ? (long)t[i / per_sample] : (long)idx;
+    const float a = coef[row * 8 + 5], b = coef[row * 8 + 6];
     out[i] = __fadd_rn(__fmul_rn(a, xs[i]), __fmul_rn(b, nz[i]));
 }
 
@@ -192,6 +193,36 @@ __global__ void postprocess_kernel(const float* __restrict__ x, const double* __
     const float v = (float)__dadd_rn(__dmul_rn((double)x[i], stdv[f]), mean[f]);
     float* dst = c < 3 ? rot : pos;
     dst[((b * nj + j) * 3 + (c % 3)) * T + t] = v;
+}
+
+// masked_l2 (reference gaussian_diffusion.py:201-213): out[b] = sum_{j,t} (a - b)^2 * mask[b,t] / (J * sum_t mask[b,t]).
+// One block per sample, fp32 partial sums per thread, tree reduce in LDS (the summation order differs from torch's).
+__global__ __launch_bounds__(256) void masked_l2_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                        const uint8_t* __restrict__ mask, float* __restrict__ out, int J,
+                                                        int T) {
+    __shared__ float ssum[256];
+    __shared__ float scnt[256];
+    const int bidx = blockIdx.x, tid = threadIdx.x;
+    const long base = (long)bidx * J * T;
+    float s = 0.0f, c = 0.0f;
+    for (long i = tid; i < (long)J * T; i += 256) {
+        const int t = i % T;
+        const float m = mask[(long)bidx * T + t] ? 1.0f : 0.0f;
+        const float d = a[base + i] - b[base + i];
+        s += d * d * m;
+    }
+    for (int t = tid; t < T; t += 256) c += mask[(long)bidx * T + t] ? 1.0f : 0.0f;
+    ssum[tid] = s;
+    scnt[tid] = c;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (tid < o) {
+            ssum[tid] += ssum[tid + o];
+            scnt[tid] += scnt[tid + o];
+        }
+        __syncthreads();
+    }
+    if (tid == 0) out[bidx] = ssum[0] / (scnt[0] * (float)J);
 }
 
 __global__ void randn_kernel(float* __restrict__ out, int batch, long per_sample, long groups, uint64_t seed,
@@ -258,8 +289,27 @@ extern "C" int gdx_q_sample(const float* x_start, const float* noise, const floa
     if (!x_start || !noise || !coef || !out) return gdx_set_error_("gdx_q_sample: null argument");
     if (count == 0) return 0;
     hipLaunchKernelGGL(gdx::q_sample_kernel, dim3((count + 255) / 256), dim3(256), 0, (hipStream_t)stream, x_start,
-                       noise, coef, idx, (long)count, out);
+                       noise, coef, idx, (const int64_t*)nullptr, (long)count, (long)count, out);
     return hipGetLastError() == hipSuccess ? 0 : gdx_set_error_("gdx_q_sample: launch failed");
+}
+
+extern "C" int gdx_q_sample_t(const float* x_start, const float* noise, const float* coef, const int64_t* t,
+                              int32_t batch, int64_t per_sample, float* out, void* stream) {
+    if (!x_start || !noise || !coef || !t || !out) return gdx_set_error_("gdx_q_sample_t: null argument");
+    const long count = (long)batch * per_sample;
+    if (count <= 0) return 0;
+    hipLaunchKernelGGL(gdx::q_sample_kernel, dim3((count + 255) / 256), dim3(256), 0, (hipStream_t)stream, x_start,
+                       noise, coef, 0, t, (long)per_sample, count, out);
+    return hipGetLastError() == hipSuccess ? 0 : gdx_set_error_("gdx_q_sample_t: launch failed");
+}
+
+extern "C" int gdx_masked_l2(const float* a, const float* b, const uint8_t* mask, float* out, int32_t batch,
+                             int32_t njoints, int32_t frames, void* stream) {
+    if (!a || !b || !mask || !out) return gdx_set_error_("gdx_masked_l2: null argument");
+    if (batch <= 0 || njoints <= 0 || frames <= 0) return 0;
+    hipLaunchKernelGGL(gdx::masked_l2_kernel, dim3(batch), dim3(256), 0, (hipStream_t)stream, a, b, mask, out, njoints,
+                       frames);
+    return hipGetLastError() == hipSuccess ? 0 : gdx_set_error_("gdx_masked_l2: launch failed");
 }
 
 extern "C" int gdx_plms_update(const gdx_plms_args_t* a, void* stream) {

@@ -173,11 +173,9 @@ class GaussianDiffusion:
             noise = th.randn_like(x_start)
         assert noise.shape == x_start.shape
         E.require_device(x_start, "x_start")
-        tv = t.reshape(-1)
-        if not bool((tv == tv[0]).all()):
-            raise NotImplementedError("q_sample with per-sample timesteps is not on the sampling path")
         coef = self.coef_table(GDX_SAMPLER_P, x_start.device)
-        return E.q_sample(E.f32c(x_start, "x_start"), E.f32c(noise, "noise"), coef, int(tv[0]))
+        tv = E.require_device(t, "t").reshape(-1).to(th.int64).contiguous()
+        return E.q_sample_t(E.f32c(x_start, "x_start"), E.f32c(noise, "noise"), coef, tv)
 
     # ------------------------------------------------------------------ one reverse step
     def _scale_timesteps(self, t):
@@ -400,8 +398,32 @@ class GaussianDiffusion:
                               cond_fn_with_grad, False, "torch", 0, 0, None)
 
     # ------------------------------------------------------------------ explicitly out of scope
-    def training_losses(self, *a, **k):
-        raise NotImplementedError("training is outside the sampling hot path (SURVEY.md section 2.1)")
+    def masked_l2(self, a, b, mask):
+        """reference :201-213; a, b [B,J,1,T], mask bool [B,1,1,T] -> [B]."""
+        return E.masked_l2(E.f32c(a, "a"), E.f32c(b, "b"), mask)
+
+    def training_losses(self, model, x_start, t, model_kwargs=None, noise=None, dataset=None):
+        """FORWARD half of the reference's training_losses (:1227-1352) in its configured mode (LossType.MSE, START_X,
+        fixed variance, lambda_vel = lambda_rcxyz = lambda_fc = 0): x_t = q_sample(x_start, t, noise), the model's x0
+        prediction, terms['rot_mse'] = masked_l2(x_start, prediction, y['mask']), terms['loss'] = rot_mse.  The values are
+        those the reference would log; there is no autograd graph behind them (training is out of scope)."""
+        from . import gaussian_diffusion as _gd
+        if self.loss_type not in (_gd.LossType.MSE, _gd.LossType.RESCALED_MSE):
+            raise NotImplementedError(self.loss_type)
+        self._check_supported()
+        for lam in ("lambda_vel", "lambda_rcxyz", "lambda_fc"):
+            if getattr(self, lam, 0.0):
+                raise NotImplementedError(f"{lam} > 0 needs the xyz / velocity terms, which are not on the path")
+        mask = model_kwargs["y"]["mask"]                       # KeyError / TypeError like the reference (:1243)
+        if noise is None:
+            noise = th.randn_like(x_start)
+        x_t = self.q_sample(x_start, t, noise=noise)
+        with th.no_grad():
+            model_output = self._call_model(model, x_t, t, model_kwargs)
+        assert model_output.shape == x_start.shape
+        terms = {"rot_mse": self.masked_l2(x_start, model_output, mask)}
+        terms["loss"] = terms["rot_mse"]
+        return terms
 
     # ------------------------------------------------------------------ PLMS (reference :995-1190)
     def _pred_xstart(self, model, x, t, clip_denoised, denoised_fn, model_kwargs):

@@ -216,6 +216,26 @@ def q_sample(x_start, noise, coef, idx):
     return out
 
 
+def q_sample_t(x_start, noise, coef, t):
+    """q_sample with per-sample timesteps (int64 [B] on the device)."""
+    lib = _lib.load()
+    out = torch.empty_like(x_start)
+    B = x_start.shape[0]
+    _lib.check(lib.gdx_q_sample_t(_ptr(x_start), _ptr(noise), _ptr(coef), _ptr(t), B, x_start.numel() // B, _ptr(out),
+                                  _stream(x_start.device)), lib)
+    return out
+
+
+def masked_l2(a, b, mask):
+    """Per-sample masked mean squared error (reference masked_l2); mask bool [B,1,1,T]."""
+    lib = _lib.load()
+    B, J, F, T = a.shape
+    m = require_device(mask, "mask").to(torch.bool).reshape(B, T).contiguous()
+    out = torch.empty(B, device=a.device, dtype=torch.float32)
+    _lib.check(lib.gdx_masked_l2(_ptr(a), _ptr(b), _ptr(m), _ptr(out), B, J * F, T, _stream(a.device)), lib)
+    return out
+
+
 def randn(shape, device, philox_seed, sample_offset=0, rng_step=0):
     lib = _lib.load()
     out = torch.empty(shape, device=device, dtype=torch.float32)

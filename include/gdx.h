@@ -163,6 +163,14 @@ int gdx_plms_update(const gdx_plms_args_t* a, void* stream);
 int gdx_q_sample(const float* x_start, const float* noise, const float* coef, int32_t idx,
                  int64_t count, float* out, void* stream);
 
+/* q_sample with per-sample timesteps t [B] (int64, device): the form training_losses uses (:1249). */
+int gdx_q_sample_t(const float* x_start, const float* noise, const float* coef, const int64_t* t, int32_t batch,
+                   int64_t per_sample, float* out, void* stream);
+/* masked_l2 (gaussian_diffusion.py:201-213): out[b] = sum_{j,t} (a-b)^2 mask[b,t] / (J * sum_t mask[b,t]);
+ * a, b [B,J,1,T] fp32, mask bool bytes [B,1,1,T], out [B].  Used by the forward half of training_losses (:1227-1352). */
+int gdx_masked_l2(const float* a, const float* b, const uint8_t* mask, float* out, int32_t batch, int32_t njoints,
+                  int32_t frames, void* stream);
+
 /* Philox N(0,1) fill, same keying as gdx_sampler_update (rng_step) -- used for x_T. */
 int gdx_randn(float* out, int32_t batch, int64_t per_sample, uint64_t philox_seed,
               uint64_t sample_offset, uint32_t rng_step, void* stream);

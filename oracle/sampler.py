@@ -168,3 +168,21 @@ def postprocess_chunk(sample_out, mean, std):
     rot = rot.view(rot.shape[:-1] + (-1, 3))
     rot = rot.view(-1, *rot.shape[2:]).permute(0, 2, 3, 1)
     return pos, rot
+
+
+# ---------------------------------------------------------------------------------------------
+def masked_l2(a, b, mask):
+    """gaussian_diffusion.py:201-213 (mask [B,1,1,T] bool)."""
+    loss = ((a - b) ** 2 * mask.float()).sum(dim=[1, 2, 3])
+    n_entries = a.shape[1] * a.shape[2]
+    return loss / (mask.sum(dim=[1, 2, 3]) * n_entries)
+
+
+def training_losses(model_fn, tab, tmap, x_start, t, y, noise):
+    """Forward half of training_losses (gaussian_diffusion.py:1227-1352) in the configured mode (LossType.MSE,
+    START_X, fixed variance, lambda_vel = lambda_rcxyz = lambda_fc = 0): x_t = q_sample(x_start, t, noise),
+    model_output = model(x_t, t), rot_mse = masked_l2(x_start, model_output, y['mask']); loss = rot_mse."""
+    x_t = q_sample(tab, x_start, t, noise)
+    out = model_fn(x_t, torch.tensor(tmap, dtype=torch.long)[t], y)
+    rot = masked_l2(x_start, out, y["mask"])
+    return {"rot_mse": rot, "loss": rot}

@@ -290,6 +290,43 @@ def gen_plms_tiny(mods, out):
         np.savez_compressed(os.path.join(out, f"plms_{arch}_tiny.npz"), **d)
 
 
+def gen_losses_tiny(mods, out):
+    """training_losses (gaussian_diffusion.py:1227-1352), forward values only, on the tiny models: per-sample timesteps,
+    explicit noise, a ragged frame mask.  The reference reads `model.model` (its DDP / CFG wrapper convention)."""
+    gd, rs = mods[3], mods[4]
+    for arch in ("mdm", "mdm_old"):
+        cfg = tiny_cfg(arch)
+        sd = init_state_dict(cfg, seed=2, perturb=True)
+        B, T = 3, 20
+        _, seedp, mfcc = synthetic_inputs(cfg, B, T, seed=5)
+        m = build_ref_model(mods, cfg, sd)
+
+        class Wrapped(torch.nn.Module):
+            def __init__(self, inner):
+                super().__init__()
+                self.model = inner
+
+            def forward(self, x, t, **kw):
+                return self.model(x, t, **kw)
+        g = torch.Generator().manual_seed(99)
+        shape = (B, cfg["njoints"], 1, T)
+        x_start = torch.randn(*shape, generator=g)
+        noise = torch.randn(*shape, generator=g)
+        mask = torch.ones(B, 1, 1, T, dtype=torch.bool)
+        mask[1, ..., 13:] = False
+        mask[2, ..., 7:] = False
+        d = {"x_start": x_start.numpy(), "noise": noise.numpy(), "mask": mask.numpy()}
+        for tag, resp, t in (("full", [1000], torch.tensor([0, 500, 999])), ("r20", [20], torch.tensor([19, 3, 0]))):
+            df = make_diffusion(gd, rs, resp)
+            with torch.no_grad():
+                terms = df.training_losses(Wrapped(m), x_start, t, model_kwargs={"y": {"seed": seedp, "mfcc": mfcc, "mask": mask}},
+                                           noise=noise)
+            d[tag + ".t"] = t.numpy()
+            for k, v in terms.items():
+                d[f"{tag}.{k}"] = v.numpy()
+        np.savez_compressed(os.path.join(out, f"losses_{arch}_tiny.npz"), **d)
+
+
 def gen_real_shapes(mods, out):
     """F4: outputs only; weights/inputs regenerate from gesturediffusion_amd.utils.init."""
     cases = {
@@ -372,12 +409,12 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--ref", default="/root/reference")
     ap.add_argument("--out", default=os.path.join(REPO, "tests", "golden"))
-    ap.add_argument("--only", default="", help="comma-separated subset: schedule,forward,loops,plms,real,negative,keys")
+    ap.add_argument("--only", default="", help="comma-separated subset: schedule,forward,loops,plms,losses,real,negative,keys")
     args = ap.parse_args()
     os.makedirs(args.out, exist_ok=True)
     torch.set_num_threads(8)
     mods = import_reference(args.ref)
-    gens = {"schedule": gen_schedule, "forward": gen_forward_tiny, "loops": gen_loops_tiny, "plms": gen_plms_tiny,
+    gens = {"schedule": gen_schedule, "forward": gen_forward_tiny, "loops": gen_loops_tiny, "plms": gen_plms_tiny, "losses": gen_losses_tiny,
             "real": gen_real_shapes, "negative": gen_negative, "keys": gen_state_dict_keys}
     for name in (args.only.split(",") if args.only else gens):
         gens[name](mods, args.out)

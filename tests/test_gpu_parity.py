@@ -587,3 +587,24 @@ def test_postprocess_chunk_bit_exact():
     pos, rot = E.postprocess(x.to(dev()), mean, std)
     wp, wr = osamp.postprocess_chunk(x, mean, std)
     assert pos.shape == (B, nj, 3, T) and torch.equal(pos.cpu(), wp.contiguous()) and torch.equal(rot.cpu(), wr.contiguous())
+
+
+@pytest.mark.parametrize("arch", ["mdm", "mdm_old"])
+@pytest.mark.parametrize("tag,resp", [("full", [1000]), ("r20", [20])])
+def test_training_losses_forward_half_vs_reference_golden(arch, tag, resp):
+    """training_losses' forward values (reference gaussian_diffusion.py:1227-1352): q_sample with per-sample
+    timesteps, native forward, masked MSE over a ragged frame mask -- against the values the reference computed."""
+    g = load_golden(f"loops_{arch}_tiny.npz")
+    gl = load_golden(f"losses_{arch}_tiny.npz")
+    d = dev()
+    m = build_model(arch, TINY, weights_from(g))
+    y = {"seed": torch.from_numpy(g["seed"]).to(d), "mfcc": torch.from_numpy(g["mfcc"]).to(d),
+         "mask": torch.from_numpy(gl["mask"]).to(d)}
+    df = _diffusion(resp)
+    terms = df.training_losses(m, torch.from_numpy(gl["x_start"]).to(d), torch.from_numpy(gl[tag + ".t"]).to(d),
+                               model_kwargs={"y": y}, noise=torch.from_numpy(gl["noise"]).to(d))
+    assert rel_err(terms["rot_mse"].cpu(), gl[tag + ".rot_mse"]) < 2e-5
+    assert rel_err(terms["loss"].cpu(), gl[tag + ".loss"]) < 2e-5
+    with pytest.raises(KeyError):
+        df.training_losses(m, torch.from_numpy(gl["x_start"]).to(d), torch.from_numpy(gl[tag + ".t"]).to(d),
+                           model_kwargs={"y": {k: v for k, v in y.items() if k != "mask"}})

@@ -173,8 +173,12 @@ def test_unsupported_modes_raise():
                               model_var_type=gd.ModelVarType.FIXED_SMALL, loss_type=gd.LossType.MSE)
     with pytest.raises(NotImplementedError):
         df.coef_table(0, "cpu")
+    with pytest.raises(NotImplementedError):       # the forward half is implemented for the configured mode only
+        gd.GaussianDiffusion(betas=gd.get_named_beta_schedule("cosine", 1000), model_mean_type=gd.ModelMeanType.START_X,
+                             model_var_type=gd.ModelVarType.FIXED_SMALL, loss_type=gd.LossType.MSE,
+                             lambda_vel=1.0).training_losses(None, None, None, model_kwargs={"y": {"mask": None}})
     with pytest.raises(NotImplementedError):
-        _diffusion([10]).training_losses(None, None, None)
+        df.coef_table(1, "cpu")
     with pytest.raises(NotImplementedError):
         _diffusion([10]).ddim_sample_loop(None, (1, 1, 1, 1), dump_steps=[0])
     with pytest.raises(NotImplementedError):

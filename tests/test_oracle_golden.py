@@ -164,6 +164,25 @@ def test_plms_tiny(arch, name):
 
 
 @pytest.mark.parametrize("arch", ["mdm", "mdm_old"])
+@pytest.mark.parametrize("tag,resp", [("full", [1000]), ("r20", [20])])
+def test_training_losses_forward_half(arch, tag, resp):
+    """training_losses' forward values (reference gaussian_diffusion.py:1227-1352): q_sample with per-sample timesteps,
+    model forward, masked MSE over a ragged frame mask."""
+    g = load_golden(f"loops_{arch}_tiny.npz")
+    gl = load_golden(f"losses_{arch}_tiny.npz")
+    p = weights_from(g)
+    cfg = dict(TINY, arch=arch)
+    y = {"seed": torch.from_numpy(g["seed"]), "mfcc": torch.from_numpy(g["mfcc"]), "mask": torch.from_numpy(gl["mask"])}
+    tab, tmap = osch.make_tables("cosine", 1000, resp)
+    with torch.no_grad():
+        terms = osamp.training_losses(lambda x, t, yy: omf.forward(p, cfg, x, t, yy), tab, tmap,
+                                      torch.from_numpy(gl["x_start"]), torch.from_numpy(gl[tag + ".t"]), y,
+                                      torch.from_numpy(gl["noise"]))
+    assert rel_err(terms["rot_mse"], gl[tag + ".rot_mse"]) < 1e-5
+    assert rel_err(terms["loss"], gl[tag + ".loss"]) < 1e-5
+
+
+@pytest.mark.parametrize("arch", ["mdm", "mdm_old"])
 def test_ddim_reverse_tiny(arch):
     g = load_golden(f"loops_{arch}_tiny.npz")
     p = weights_from(g)
