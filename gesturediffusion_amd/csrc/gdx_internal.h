@@ -95,7 +95,10 @@ hipError_t launch_mfcc_project(const float* mfcc, const float* W, int ldw, const
 // per conditioning instead of a [B,d] x [d,d] linear per step)
 hipError_t launch_token0(const float* temb, int tstride, const float* seed_emb, const float* pe0,
                          float* enc, _Float16* enc16, float* coa, const float* c2t_row, const float* c2_seed, float* c2,
-                         int B, int Bmod, int S, int d, hipStream_t s);
+                         const int* state, int B, int Bmod, int S, int d, hipStream_t s);
+// graph replay of the sampling loop: device-resident {schedule index, executed-step number} (sampler.hip)
+hipError_t launch_set_state(int* st, int idx, int k, hipStream_t s);
+hipError_t launch_advance_state(int* st, hipStream_t s);
 // V2 front end: RoPE -> causal local attention (window, look back one window) -> RoPE at pos+1,
 // written into enc[b][t+1][:].   xseq [B*T][d];  cos/sin tables [>=T+1][e/2], e = d/heads.
 hipError_t launch_local_attention(const float* xseq, const float* cosT, const float* sinT, float* enc,

@@ -65,6 +65,11 @@ struct UpdateDev {
     uint64_t seed, sample_offset;
     uint32_t rng_step;
     float *out, *pred;
+    // graph replay (gdx_sample_loop): when `state` is set the step-dependent values come from device memory, so one
+    // captured step can be replayed for every step: state[0] = schedule index, state[1] = executed-step number k
+    // (rng_step = k + 1, noise = noise + k * noise_stride)
+    const int* state;
+    long noise_stride;
 };
 
 template <bool VEC>
@@ -75,8 +80,10 @@ __global__ __launch_bounds__(256) void update_kernel(const UpdateDev a) {
     const uint32_t grp = gid - (long)b * a.groups;
     const long e0 = (long)b * a.per_sample + 4L * grp;
     const int nval = VEC ? 4 : (int)min(4L, a.per_sample - 4L * grp);
-    const long idx = a.t ? a.t[b] : a.step_index;
+    const long idx = a.state ? a.state[0] : (a.t ? a.t[b] : a.step_index);
     const float* c = a.coef + idx * 8;
+    const uint32_t rng_step = a.state ? (uint32_t)a.state[1] + 1u : a.rng_step;
+    const float* noise = a.noise && a.state ? a.noise + (long)a.state[1] * a.noise_stride : a.noise;
 
     f32x4 x, x0, z;
     if (VEC) {
@@ -98,13 +105,13 @@ __global__ __launch_bounds__(256) void update_kernel(const UpdateDev a) {
         for (int i = 0; i < 4; ++i)
             if (i < nval && a.mask[e0 + i]) x0[i] = a.motion[e0 + i];
     }
-    if (a.noise) {
+    if (noise) {
         const long z0 = a.const_noise ? 4L * grp : e0;
-        if (VEC) z = *reinterpret_cast<const f32x4*>(a.noise + z0);
-        else for (int i = 0; i < 4; ++i) z[i] = i < nval ? a.noise[z0 + i] : 0.f;
+        if (VEC) z = *reinterpret_cast<const f32x4*>(noise + z0);
+        else for (int i = 0; i < 4; ++i) z[i] = i < nval ? noise[z0 + i] : 0.f;
     } else {
         const uint64_t sample = a.const_noise ? 0ull : a.sample_offset + (uint64_t)b;
-        z = philox_normal4(a.seed, sample, a.rng_step, grp);
+        z = philox_normal4(a.seed, sample, rng_step, grp);
     }
     f32x4 r;
     if (a.kind == GDX_SAMPLER_P) {
@@ -259,7 +266,32 @@ hipError_t launch_cfg_blend(const float* c, const float* u, const float* scale, 
 
 extern "C" int gdx_set_error_(const char* msg);   // api.hip
 
+namespace gdx {
+__global__ void set_state_kernel(int* st, int idx, int k) { st[0] = idx; st[1] = k; }
+__global__ void advance_state_kernel(int* st) { st[0] -= 1; st[1] += 1; }
+
+hipError_t launch_set_state(int* st, int idx, int k, hipStream_t s) {
+    hipLaunchKernelGGL(set_state_kernel, dim3(1), dim3(1), 0, s, st, idx, k);
+    return hipGetLastError();
+}
+hipError_t launch_advance_state(int* st, hipStream_t s) {
+    hipLaunchKernelGGL(advance_state_kernel, dim3(1), dim3(1), 0, s, st);
+    return hipGetLastError();
+}
+}  // namespace gdx
+
+static int sampler_update_impl(const gdx_update_args_t* a, const int* state, long noise_stride, void* stream);
+
 extern "C" int gdx_sampler_update(const gdx_update_args_t* a, void* stream) {
+    return sampler_update_impl(a, nullptr, 0, stream);
+}
+
+// internal: the update of a captured step (see UpdateDev::state)
+int gdx_sampler_update_state_(const gdx_update_args_t* a, const int* state, long noise_stride, void* stream) {
+    return sampler_update_impl(a, state, noise_stride, stream);
+}
+
+static int sampler_update_impl(const gdx_update_args_t* a, const int* state, long noise_stride, void* stream) {
     using namespace gdx;
     if (!a || !a->coef || !a->x || !a->x0_cond || !a->out) return gdx_set_error_("gdx_sampler_update: null argument");
     if (a->x0_uncond && !a->scale) return gdx_set_error_("gdx_sampler_update: CFG needs scale");
@@ -274,6 +306,7 @@ extern "C" int gdx_sampler_update(const gdx_update_args_t* a, void* stream) {
     d.mask = a->inpaint_mask; d.motion = a->inpaint_motion; d.noise = a->noise;
     d.const_noise = a->const_noise; d.seed = a->philox_seed; d.sample_offset = a->sample_offset;
     d.rng_step = a->rng_step; d.out = a->out; d.pred = a->pred_xstart;
+    d.state = state; d.noise_stride = noise_stride;
     const long total = d.groups * d.batch;
     if (total == 0) return 0;
     const dim3 grid((total + 255) / 256), block(256);

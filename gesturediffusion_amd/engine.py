@@ -67,6 +67,10 @@ class Engine:
         except Exception:  # noqa: BLE001 - interpreter shutdown
             pass
 
+    def set_graph_replay(self, on):
+        """hipGraph replay of the step inside sample_loop (off by default; see include/gdx.h)."""
+        _lib.check(self.lib.gdx_set_graph_replay(self.handle, int(bool(on))), self.lib)
+
     # ------------------------------------------------------------------ weights
     def set_weight(self, name, t):
         t = f32c(t, name)

@@ -210,6 +210,12 @@ typedef struct {
 } gdx_loop_args_t;
 int gdx_sample_loop(gdx_handle_t h, const gdx_loop_args_t* a, void* stream);
 
+/* Replay ONE captured step as a hipGraph inside gdx_sample_loop (device-resident step state; the graph runs on an
+ * internal stream ordered after / before `stream` by events).  Results are bit-identical to the eager loop.  Off by
+ * default: on ROCm 7.2 the replay measured ~10 % slower than eager launches even for launch-dominated small batches
+ * (csrc/api.hip, gdx_sample_loop).  Ignored while taps, dump_steps or in-situ profiling are active. */
+int gdx_set_graph_replay(gdx_handle_t h, int32_t on);
+
 /* ---- measurement helpers (bench.py only) ------------------------------------------------ */
 /* Time `iters` launches of the FFN-1 GEMM (bias+GELU epilogue) of layer 0 on the current
  * workspace shape with HIP events on `stream`; returns average microseconds per launch. */

@@ -608,3 +608,45 @@ def test_training_losses_forward_half_vs_reference_golden(arch, tag, resp):
     with pytest.raises(KeyError):
         df.training_losses(m, torch.from_numpy(gl["x_start"]).to(d), torch.from_numpy(gl[tag + ".t"]).to(d),
                            model_kwargs={"y": {k: v for k, v in y.items() if k != "mask"}})
+
+
+@pytest.mark.parametrize("arch", ["mdm", "mdm_old"])
+@pytest.mark.parametrize("name", ["p20_cfg_inpaint", "ddim10_eta05", "p20_const_noise"])
+def test_graph_replay_matches_eager_loop(arch, name):
+    """gdx_set_graph_replay: one captured step replayed as a hipGraph (device-resident step state) gives bit-identical
+    results to the eager loop and matches the reference fixture (noise tape, CFG, inpainting, const_noise, DDIM eta);
+    a Philox loop is compared graph vs eager as well."""
+    from gesturediffusion_amd.model.cfg_sampler import ClassifierFreeSampleModel
+    g = load_golden(f"loops_{arch}_tiny.npz")
+    d = dev()
+    m = build_model(arch, TINY, weights_from(g))
+    tape = torch.from_numpy(g["tape"]).to(d)
+    y = {"seed": torch.from_numpy(g["seed"]).to(d), "mfcc": torch.from_numpy(g["mfcc"]).to(d)}
+    model = m
+    if "cfg" in name:
+        y["scale"] = torch.from_numpy(g["scale"]).to(d)
+        model = ClassifierFreeSampleModel(m)
+    if "inpaint" in name:
+        y["inpainting_mask"] = torch.from_numpy(g["inpainting_mask"]).to(d)
+        y["inpainted_motion"] = torch.from_numpy(g["inpainted_motion"]).to(d)
+    kw = dict(clip_denoised=False, model_kwargs={"y": y})
+    if name.startswith("p20"):
+        df, fn = _diffusion([20]), "p_sample_loop"
+    else:
+        df, fn = _diffusion("ddim10"), "ddim_sample_loop"
+    if name == "p20_const_noise":
+        kw["const_noise"] = True
+    if name == "ddim10_eta05":
+        kw["eta"] = 0.5
+    shape = tuple(tape[0].shape)
+    eng = m._get_engine(d)
+    eager = getattr(df, fn)(model, shape, noise_tape=tape, **kw)
+    eager_px = getattr(df, fn)(model, shape, rng="philox", philox_seed=5, **kw)
+    eng.set_graph_replay(True)
+    try:
+        replay = getattr(df, fn)(model, shape, noise_tape=tape, **kw)
+        replay_px = getattr(df, fn)(model, shape, rng="philox", philox_seed=5, **kw)
+    finally:
+        eng.set_graph_replay(False)
+    assert torch.equal(replay, eager) and torch.equal(replay_px, eager_px)
+    assert rel_err(replay.cpu(), g[name]) < LOOP_TOL
