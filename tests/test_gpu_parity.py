@@ -650,3 +650,25 @@ def test_graph_replay_matches_eager_loop(arch, name):
         eng.set_graph_replay(False)
     assert torch.equal(replay, eager) and torch.equal(replay_px, eager_px)
     assert rel_err(replay.cpu(), g[name]) < LOOP_TOL
+
+
+def test_fp16_mode_taps_match_fp32_taps():
+    """Parity taps in the fp16 mode (fp32 copies written by the fp16 GEMM / LayerNorm epilogues only when taps are kept):
+    every encoder-layer activation stays within the fp16 tolerance of the fp32 path's."""
+    from gesturediffusion_amd.utils.init import init_state_dict, synthetic_inputs
+    cfg = dict(arch="mdm", njoints=48, nfeats=1, latent_dim=512, ff_size=1024, num_layers=3, num_heads=4, seed_poses=10)
+    sd = init_state_dict(cfg, seed=1, perturb=True)
+    d = dev()
+    x, seedp, mfcc = synthetic_inputs(cfg, 2, 30, seed=2)
+    t = torch.tensor([17, 803], device=d)
+    y = {"seed": seedp.to(d), "mfcc": mfcc.to(d)}
+    taps = {}
+    for dt in ("fp32", "fp16"):
+        m = build_model("mdm", cfg, sd)
+        m.compute_dtype = dt
+        eng = m._get_engine(d)
+        eng.keep_taps(True)
+        m(x.to(d), t, y)
+        taps[dt] = [eng.tap(i, 2 * 2 * 31, 512, d)[: 2 * 31].cpu() for i in range(cfg["num_layers"] + 1)]
+    for a, b in zip(taps["fp32"], taps["fp16"]):
+        assert rel_err(b, a) < F16_TOL and not torch.equal(a, b)
