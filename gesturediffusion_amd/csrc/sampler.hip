@@ -70,6 +70,9 @@ struct UpdateDev {
     // (rng_step = k + 1, noise = noise + k * noise_stride)
     const int* state;
     long noise_stride;
+    // cond_fn guidance (reference :418-494): gradient tensor and, for DDIM, the per-step sqrt(1 - alpha_bar) table
+    const float* grad;
+    const float* gcoef;
 };
 
 template <bool VEC>
@@ -117,14 +120,21 @@ __global__ __launch_bounds__(256) void update_kernel(const UpdateDev a) {
     if (a.kind == GDX_SAMPLER_P) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const float mean = __fadd_rn(__fmul_rn(c[0], x0[i]), __fmul_rn(c[1], x[i]));
+            float mean = __fadd_rn(__fmul_rn(c[0], x0[i]), __fmul_rn(c[1], x[i]));
+            if (a.grad && i < nval) mean = __fadd_rn(mean, __fmul_rn(c[3], a.grad[e0 + i]));   // condition_mean: + variance * gradient
             r[i] = __fadd_rn(mean, __fmul_rn(c[2], z[i]));
         }
     } else {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const float eps = __fdiv_rn(__fsub_rn(__fmul_rn(c[0], x[i]), x0[i]), c[1]);
-            const float mean = __fadd_rn(__fmul_rn(x0[i], c[2]), __fmul_rn(c[3], eps));
+            float xs = x0[i];
+            if (a.grad && i < nval) {                         // condition_score: eps - sqrt(1 - alpha_bar) * gradient -> pred_xstart
+                const float e1 = __fdiv_rn(__fsub_rn(__fmul_rn(c[0], x[i]), xs), c[1]);
+                const float e2 = __fsub_rn(e1, __fmul_rn(a.gcoef[idx], a.grad[e0 + i]));
+                xs = __fsub_rn(__fmul_rn(c[0], x[i]), __fmul_rn(c[1], e2));
+            }
+            const float eps = __fdiv_rn(__fsub_rn(__fmul_rn(c[0], x[i]), xs), c[1]);
+            const float mean = __fadd_rn(__fmul_rn(xs, c[2]), __fmul_rn(c[3], eps));
             r[i] = __fadd_rn(mean, __fmul_rn(c[4], z[i]));
         }
     }
@@ -307,6 +317,8 @@ static int sampler_update_impl(const gdx_update_args_t* a, const int* state, lon
     d.const_noise = a->const_noise; d.seed = a->philox_seed; d.sample_offset = a->sample_offset;
     d.rng_step = a->rng_step; d.out = a->out; d.pred = a->pred_xstart;
     d.state = state; d.noise_stride = noise_stride;
+    d.grad = a->cond_grad; d.gcoef = a->cond_coef;
+    if (d.grad && a->kind != GDX_SAMPLER_P && !d.gcoef) return gdx_set_error_("gdx_sampler_update: cond_grad needs cond_coef for DDIM");
     const long total = d.groups * d.batch;
     if (total == 0) return 0;
     const dim3 grid((total + 255) / 256), block(256);

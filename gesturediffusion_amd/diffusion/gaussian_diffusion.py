@@ -11,7 +11,7 @@ coefficient rows; every per-element operation runs in libgdx.so:
   * `gdx_sample_loop`     the whole loop enqueued from C++ with in-kernel Philox noise
 
 Supported configuration = the one the reference hard-codes (`utils/model_util.py:37-72`):
-START_X mean, FIXED_SMALL / FIXED_LARGE variance.  Training losses, PLMS, cond_fn guidance and
+START_X mean, FIXED_SMALL / FIXED_LARGE variance.  The backward half of training, cond_fn_with_grad and
 learned variances are outside the hot path and raise NotImplementedError.
 
 RNG.  `rng="torch"` (default) draws x_T with `torch.randn` and one `torch.randn_like` per step
@@ -147,6 +147,7 @@ class GaussianDiffusion:
             c[:, 0] = f32(self.posterior_mean_coef1)
             c[:, 1] = f32(self.posterior_mean_coef2)
             c[:, 2] = nz * th.exp(0.5 * f32(logvar))
+            c[:, 3] = f32(self._model_variance_tables()[0])     # model variance, used by condition_mean
         else:
             ab, abp = f32(self.alphas_cumprod), f32(self.alphas_cumprod_prev)
             sigma = (0.0 if eta == "reverse" else eta) * th.sqrt((1 - abp) / (1 - ab)) * th.sqrt(1 - ab / abp)
@@ -186,10 +187,20 @@ class GaussianDiffusion:
     def _call_model(self, model, x, t, model_kwargs):
         return model(x, self._scale_timesteps(t), **model_kwargs)
 
+    def _cond_coef(self, device):
+        """(1 - alpha_bar).sqrt() in fp32, the factor of condition_score (reference :463-466)."""
+        key = ("cond", str(device))
+        if key not in self._coef_cache:
+            ab = th.from_numpy(np.ascontiguousarray(self.alphas_cumprod, dtype=np.float64)).float()
+            self._coef_cache[key] = (1 - ab).sqrt().to(device)
+        return self._coef_cache[key]
+
+    def _call_cond_fn(self, cond_fn, x, t, model_kwargs):
+        """cond_fn(x, t, **model_kwargs) -> gradient of log p(y | x) (reference condition_mean / condition_score)."""
+        return cond_fn(x, self._scale_timesteps(t), **model_kwargs)
+
     def _step(self, kind, model, x, t, clip_denoised, denoised_fn, cond_fn, model_kwargs, eta=0.0, const_noise=False,
               noise=None):
-        if cond_fn is not None:
-            raise NotImplementedError("cond_fn guidance is outside the sampling hot path (SURVEY.md 8f N4)")
         if model_kwargs is None:
             model_kwargs = {}
         self._check_supported()
@@ -220,10 +231,20 @@ class GaussianDiffusion:
         xc = E.f32c(x, "x")
         out = th.empty_like(xc)
         pred = th.empty_like(xc)
+        grad = gcoef = None
+        if cond_fn is not None:
+            # condition_mean (ancestral) / condition_score (DDIM), reference :418-494: the gradient is the user's callable,
+            # its application to the mean / eps happens inside the fused update kernel
+            if eta == "reverse":
+                raise NotImplementedError("ddim_reverse_sample takes no cond_fn")
+            grad = E.f32c(self._call_cond_fn(cond_fn, x, t, model_kwargs), "cond_fn gradient")
+            assert grad.shape == x.shape
+            gcoef = self._cond_coef(x.device) if kind == GDX_SAMPLER_DDIM else None
         E.sampler_update(kind, self.coef_table(kind, x.device, eta), xc, x0, out, t=t.to(th.int64).contiguous(),
                          inpaint_mask=mask.contiguous() if mask is not None else None,
                          inpaint_motion=E.f32c(motion, "inpainted_motion") if motion is not None else None,
-                         noise=E.f32c(noise, "noise"), const_noise=const_noise, pred_xstart=pred)
+                         noise=E.f32c(noise, "noise"), const_noise=const_noise, pred_xstart=pred, cond_grad=grad,
+                         cond_coef=gcoef)
         return {"sample": out, "pred_xstart": pred}
 
     def p_sample(self, model, x, t, clip_denoised=True, denoised_fn=None, cond_fn=None, model_kwargs=None,
@@ -276,12 +297,12 @@ class GaussianDiffusion:
     def _loop(self, kind, model, shape, noise, clip_denoised, denoised_fn, cond_fn, model_kwargs, device, progress,
               eta, skip_timesteps, init_image, randomize_class, cond_fn_with_grad, const_noise, rng, philox_seed,
               sample_offset, noise_tape, dump_steps=None):
-        if cond_fn is not None or cond_fn_with_grad or randomize_class:
-            raise NotImplementedError("cond_fn / randomize_class are outside the sampling hot path")
+        if cond_fn_with_grad or randomize_class:
+            raise NotImplementedError("cond_fn_with_grad / randomize_class are outside the sampling hot path")
         device, img, indices = self._prepare_loop(model, shape, noise, device, skip_timesteps, init_image, rng,
                                                   philox_seed, sample_offset, noise_tape)
         fused = (rng == "philox" or noise_tape is not None) and _is_native(model) and not clip_denoised \
-            and denoised_fn is None and not progress
+            and denoised_fn is None and not progress and cond_fn is None
         if fused:
             yield from self._fused_loop(kind, model, img, indices, model_kwargs, eta, const_noise, philox_seed,
                                         sample_offset, noise_tape, dump_steps)
@@ -297,7 +318,7 @@ class GaussianDiffusion:
             elif rng == "philox":
                 z = E.randn(tuple(shape), device, philox_seed, 0 if const_noise else sample_offset, k + 1)
             with th.no_grad():
-                out = self._step(kind, model, img, t, clip_denoised, denoised_fn, None, model_kwargs, eta=eta,
+                out = self._step(kind, model, img, t, clip_denoised, denoised_fn, cond_fn, model_kwargs, eta=eta,
                                  const_noise=const_noise, noise=z)
             yield out
             img = out["sample"]

@@ -63,6 +63,9 @@ class SpacedDiffusion(GaussianDiffusion):
     def _call_model(self, model, x, t, model_kwargs):
         return self._wrap_model(model)(x, t, **model_kwargs)
 
+    def _call_cond_fn(self, cond_fn, x, t, model_kwargs):
+        return self._wrap_model(cond_fn)(x, t, **model_kwargs)        # reference respace.py:99-103
+
     def _timestep_map(self):
         return list(self.timestep_map)
 

@@ -163,7 +163,7 @@ class Engine:
 # ---------------------------------------------------------------------- standalone kernels
 def sampler_update(kind, coef, x, x0_cond, out, t=None, step_index=0, x0_uncond=None, scale=None, inpaint_mask=None,
                    inpaint_motion=None, noise=None, const_noise=False, philox_seed=0, sample_offset=0, rng_step=0,
-                   pred_xstart=None):
+                   pred_xstart=None, cond_grad=None, cond_coef=None):
     lib = _lib.load()
     B, J, F, T = x.shape
     a = _lib.UpdateArgs(kind=kind, batch=B, njoints=J * F, frames=T, coef=coef.data_ptr(),
@@ -174,7 +174,9 @@ def sampler_update(kind, coef, x, x0_cond, out, t=None, step_index=0, x0_uncond=
                         inpaint_motion=inpaint_motion.data_ptr() if inpaint_motion is not None else None,
                         noise=noise.data_ptr() if noise is not None else None, const_noise=int(const_noise),
                         philox_seed=philox_seed, sample_offset=sample_offset, rng_step=rng_step, out=out.data_ptr(),
-                        pred_xstart=pred_xstart.data_ptr() if pred_xstart is not None else None)
+                        pred_xstart=pred_xstart.data_ptr() if pred_xstart is not None else None,
+                        cond_grad=cond_grad.data_ptr() if cond_grad is not None else None,
+                        cond_coef=cond_coef.data_ptr() if cond_coef is not None else None)
     _lib.check(lib.gdx_sampler_update(C.byref(a), _stream(x.device)), lib)
     return out
 

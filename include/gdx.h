@@ -132,6 +132,12 @@ typedef struct {
     uint32_t rng_step;
     float* out;                /* x_{t-1}; may alias x */
     float* pred_xstart;        /* NULL or [B,J,1,T]: x0 after CFG/inpainting */
+    /* cond_fn guidance (gaussian_diffusion.py:418-494); both NULL when unused:
+     *   P   : mean += c[3] * cond_grad            (condition_mean; c[3] = model variance of the step)
+     *   DDIM: eps -= cond_coef[idx] * cond_grad, pred_xstart recomputed from it (condition_score;
+     *         cond_coef[idx] = sqrt(1 - alpha_bar) in fp32, device [num_steps]) */
+    const float* cond_grad;    /* [B,J,1,T] gradient returned by cond_fn */
+    const float* cond_coef;
 } gdx_update_args_t;
 int gdx_sampler_update(const gdx_update_args_t* a, void* stream);
 

@@ -186,3 +186,22 @@ def training_losses(model_fn, tab, tmap, x_start, t, y, noise):
     out = model_fn(x_t, torch.tensor(tmap, dtype=torch.long)[t], y)
     rot = masked_l2(x_start, out, y["mask"])
     return {"rot_mse": rot, "loss": rot}
+
+
+# ---------------------------------------------------------------------------------------------
+# cond_fn guidance (reference gaussian_diffusion.py:418-494; respace.py:99-103 wraps cond_fn so it sees mapped timesteps)
+def p_sample_step_cond(tab, x0, x, t, noise, grad):
+    """p_sample :496-548 with condition_mean :418-433: mean + variance * gradient (FIXED_SMALL variance)."""
+    mean = extract(tab.posterior_mean_coef1, t) * x0 + extract(tab.posterior_mean_coef2, t) * x
+    mean = mean.float() + extract(tab.posterior_variance, t) * grad.float()
+    nonzero = (t != 0).float().view(-1, 1, 1, 1)
+    return mean + nonzero * torch.exp(0.5 * extract(tab.posterior_log_variance_clipped, t)) * noise
+
+
+def ddim_step_cond(tab, x0, x, t, noise, grad, eta=0.0):
+    """ddim_sample :732-782 with condition_score :452-472: eps <- eps - sqrt(1 - alpha_bar) * gradient, pred_xstart from it."""
+    ab = extract(tab.alphas_cumprod, t)
+    eps = predict_eps(tab, x0, x, t)
+    eps = eps - (1 - ab).sqrt() * grad
+    x0c = predict_xstart(tab, eps, x, t)
+    return ddim_step(tab, x0c, x, t, noise, eta)

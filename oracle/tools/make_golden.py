@@ -290,6 +290,36 @@ def gen_plms_tiny(mods, out):
         np.savez_compressed(os.path.join(out, f"plms_{arch}_tiny.npz"), **d)
 
 
+def cond_fn_fixture(x, t, **kwargs):
+    """Deterministic stand-in for a classifier gradient (the reference has no classifier): smooth in x, depends on t."""
+    return 0.05 * torch.sin(x) * (1.0 + t.view(-1, 1, 1, 1).float() / 1000.0)
+
+
+def gen_guided_tiny(mods, out):
+    """p_sample_loop / ddim_sample_loop with cond_fn (condition_mean / condition_score, :418-494) on the tiny models,
+    same inputs and noise tape as loops_{arch}_tiny.npz (outputs only)."""
+    gd, rs = mods[3], mods[4]
+    for arch in ("mdm", "mdm_old"):
+        cfg = tiny_cfg(arch)
+        sd = init_state_dict(cfg, seed=2, perturb=True)
+        B, T = 3, 20
+        _, seedp, mfcc = synthetic_inputs(cfg, B, T, seed=5)
+        m = build_ref_model(mods, cfg, sd)
+        g = torch.Generator().manual_seed(1234)
+        shape = (B, cfg["njoints"], 1, T)
+        tape = torch.randn(22, *shape, generator=g)
+        y = {"seed": seedp, "mfcc": mfcc}
+        d = {}
+        for name, kind, resp, kw in (("p20_guided", "p", [20], {}), ("ddim10_guided", "ddim", "ddim10", {}),
+                                     ("ddim10_eta05_guided", "ddim", "ddim10", {"eta": 0.5})):
+            df = make_diffusion(gd, rs, resp)
+            fn = df.p_sample_loop if kind == "p" else df.ddim_sample_loop
+            with TapeNoise(tape[1:]):
+                d[name] = fn(m, shape, noise=tape[0].clone(), clip_denoised=False, model_kwargs={"y": y}, progress=False,
+                             cond_fn=cond_fn_fixture, **kw).numpy()
+        np.savez_compressed(os.path.join(out, f"guided_{arch}_tiny.npz"), **d)
+
+
 def gen_losses_tiny(mods, out):
     """training_losses (gaussian_diffusion.py:1227-1352), forward values only, on the tiny models: per-sample timesteps,
     explicit noise, a ragged frame mask.  The reference reads `model.model` (its DDP / CFG wrapper convention)."""
@@ -409,12 +439,12 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--ref", default="/root/reference")
     ap.add_argument("--out", default=os.path.join(REPO, "tests", "golden"))
-    ap.add_argument("--only", default="", help="comma-separated subset: schedule,forward,loops,plms,losses,real,negative,keys")
+    ap.add_argument("--only", default="", help="comma-separated subset: schedule,forward,loops,plms,losses,guided,real,negative,keys")
     args = ap.parse_args()
     os.makedirs(args.out, exist_ok=True)
     torch.set_num_threads(8)
     mods = import_reference(args.ref)
-    gens = {"schedule": gen_schedule, "forward": gen_forward_tiny, "loops": gen_loops_tiny, "plms": gen_plms_tiny, "losses": gen_losses_tiny,
+    gens = {"schedule": gen_schedule, "forward": gen_forward_tiny, "loops": gen_loops_tiny, "plms": gen_plms_tiny, "losses": gen_losses_tiny, "guided": gen_guided_tiny,
             "real": gen_real_shapes, "negative": gen_negative, "keys": gen_state_dict_keys}
     for name in (args.only.split(",") if args.only else gens):
         gens[name](mods, args.out)

@@ -672,3 +672,52 @@ def test_fp16_mode_taps_match_fp32_taps():
         taps[dt] = [eng.tap(i, 2 * 2 * 31, 512, d)[: 2 * 31].cpu() for i in range(cfg["num_layers"] + 1)]
     for a, b in zip(taps["fp32"], taps["fp16"]):
         assert rel_err(b, a) < F16_TOL and not torch.equal(a, b)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# cond_fn guidance: condition_mean / condition_score, reference gaussian_diffusion.py:418-494
+def _cond_fn_fixture(x, t, **kwargs):
+    return 0.05 * torch.sin(x) * (1.0 + t.view(-1, 1, 1, 1).float() / 1000.0)
+
+
+@pytest.mark.parametrize("kind,eta", [("p", 0.0), ("ddim", 0.0), ("ddim", 0.5)])
+def test_guided_update_bit_exact(kind, eta):
+    """The fused update with a cond_fn gradient against the torch-CPU expression of the reference: identical bits."""
+    from gesturediffusion_amd import engine as E
+    from oracle import sampler as osamp
+    from oracle import schedule as osch
+    tab, _ = osch.make_tables("cosine", 1000, [10])
+    df = _diffusion([10])
+    d = dev()
+    g = torch.Generator().manual_seed(11)
+    shape = (5, 7, 1, 13)
+    x, x0, z, gr = (torch.randn(shape, generator=g) for _ in range(4))
+    t = torch.tensor([0, 1, 5, 9, 0])
+    if kind == "p":
+        want = osamp.p_sample_step_cond(tab, x0, x, t, z, gr)
+    else:
+        want = osamp.ddim_step_cond(tab, x0, x, t, z, gr, eta)
+    code = 0 if kind == "p" else 1
+    out = torch.empty(shape, device=d)
+    E.sampler_update(code, df.coef_table(code, d, eta), x.to(d), x0.to(d), out, t=t.to(d), noise=z.to(d),
+                     cond_grad=gr.to(d), cond_coef=df._cond_coef(d) if kind == "ddim" else None)
+    assert torch.equal(out.cpu(), want)
+
+
+@pytest.mark.parametrize("arch", ["mdm", "mdm_old"])
+@pytest.mark.parametrize("name,fn,resp,eta", [("p20_guided", "p_sample_loop", [20], None), ("ddim10_guided", "ddim_sample_loop", "ddim10", 0.0),
+                                              ("ddim10_eta05_guided", "ddim_sample_loop", "ddim10", 0.5)])
+def test_guided_loops_vs_reference_golden(arch, name, fn, resp, eta):
+    """Loops with cond_fn against the reference's (same noise tape): the user's gradient callable runs in torch on the
+    device, its application to the mean / eps inside the fused update kernel."""
+    g = load_golden(f"loops_{arch}_tiny.npz")
+    gg = load_golden(f"guided_{arch}_tiny.npz")
+    d = dev()
+    m = build_model(arch, TINY, weights_from(g))
+    tape = torch.from_numpy(g["tape"]).to(d)
+    y = {"seed": torch.from_numpy(g["seed"]).to(d), "mfcc": torch.from_numpy(g["mfcc"]).to(d)}
+    kw = dict(clip_denoised=False, model_kwargs={"y": y}, cond_fn=_cond_fn_fixture, noise_tape=tape)
+    if eta is not None:
+        kw["eta"] = eta
+    r = getattr(_diffusion(resp), fn)(m, tuple(tape[0].shape), **kw)
+    assert rel_err(r.cpu(), gg[name]) < LOOP_TOL, name

@@ -163,6 +163,39 @@ def test_plms_tiny(arch, name):
         osamp.plms_loop(fn, tab, tmap, x_T.shape, x_T, y, order=1)
 
 
+def cond_fn_fixture(x, t, **kwargs):
+    """The stand-in gradient function the fixtures were generated with (oracle/tools/make_golden.py)."""
+    return 0.05 * torch.sin(x) * (1.0 + t.view(-1, 1, 1, 1).float() / 1000.0)
+
+
+@pytest.mark.parametrize("arch", ["mdm", "mdm_old"])
+@pytest.mark.parametrize("name,kind,resp,eta", [("p20_guided", "p", [20], 0.0), ("ddim10_guided", "ddim", "ddim10", 0.0),
+                                                ("ddim10_eta05_guided", "ddim", "ddim10", 0.5)])
+def test_guided_loops_tiny(arch, name, kind, resp, eta):
+    """cond_fn guidance: condition_mean in p_sample, condition_score in ddim_sample (reference :418-494); cond_fn sees
+    the timesteps mapped through the respacing (respace.py:99-103)."""
+    g = load_golden(f"loops_{arch}_tiny.npz")
+    gg = load_golden(f"guided_{arch}_tiny.npz")
+    p = weights_from(g)
+    cfg = dict(TINY, arch=arch)
+    y = {"seed": torch.from_numpy(g["seed"]), "mfcc": torch.from_numpy(g["mfcc"])}
+    tape = torch.from_numpy(g["tape"])
+    tab, tmap = osch.make_tables("cosine", 1000, resp)
+    mapt = torch.tensor(tmap)
+    img = tape[0]
+    B = img.shape[0]
+    with torch.no_grad():
+        for k, i in enumerate(range(tab.num_timesteps - 1, -1, -1)):
+            t = torch.tensor([i] * B)
+            x0 = omf.forward(p, cfg, img, mapt[t], y)
+            grad = cond_fn_fixture(img, mapt[t])
+            if kind == "p":
+                img = osamp.p_sample_step_cond(tab, x0, img, t, tape[1 + k], grad)
+            else:
+                img = osamp.ddim_step_cond(tab, x0, img, t, tape[1 + k], grad, eta)
+    assert rel_err(img, gg[name]) < 2e-5, name
+
+
 @pytest.mark.parametrize("arch", ["mdm", "mdm_old"])
 @pytest.mark.parametrize("tag,resp", [("full", [1000]), ("r20", [20])])
 def test_training_losses_forward_half(arch, tag, resp):
