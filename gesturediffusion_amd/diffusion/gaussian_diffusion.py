@@ -459,19 +459,26 @@ class GaussianDiffusion:
         element-wise arithmetic runs in gdx_plms_update with the reference's op order."""
         if not int(order) or not 1 <= order <= 4:
             raise ValueError('order is invalid (should be int from 1-4).')
-        if cond_fn is not None or cond_fn_with_grad:
-            raise NotImplementedError("cond_fn guidance is outside the sampling hot path (SURVEY.md 8f N4)")
+        if cond_fn_with_grad:
+            raise NotImplementedError("cond_fn_with_grad needs autograd through the denoiser (outside the hot path)")
         coef = self.coef_table(GDX_SAMPLER_DDIM, x.device, 0.0)
         xc = E.f32c(x, "x")
         tt = t.to(th.int64).contiguous()
-        x0 = self._pred_xstart(model, xc, tt, clip_denoised, denoised_fn, model_kwargs)
-        eps = E.plms_update(0, coef, tt, xc, x0)
+
+        def get_model_output(xx, ts):
+            """(eps, pred_xstart used downstream, original pred_xstart), reference get_model_output :1015-1041."""
+            orig = self._pred_xstart(model, xx, ts, clip_denoised, denoised_fn, model_kwargs)
+            used = orig
+            if cond_fn is not None:                       # condition_score (:452-472)
+                grad = E.f32c(self._call_cond_fn(cond_fn, xx, ts, model_kwargs), "cond_fn gradient")
+                used = E.plms_update(7, coef, ts, xx, orig, eps=[grad, self._cond_coef(xx.device)])
+            return E.plms_update(0, coef, ts, xx, used), used, orig
+        eps, x0, x0_orig = get_model_output(xc, tt)
         if order > 1 and old_out is None:
             old_eps = [eps]
             mean_pred = E.plms_update(6, coef, tt, None, x0, eps=[eps])
             t2 = (tt - 1) % self.num_timesteps            # t - 1 (a negative index wraps in the reference's table gather)
-            x0_2 = self._pred_xstart(model, mean_pred, t2, clip_denoised, denoised_fn, model_kwargs)
-            eps_2 = E.plms_update(0, coef, t2, mean_pred, x0_2)
+            eps_2, _, _ = get_model_output(mean_pred, t2)
             sample = E.plms_update(5, coef, tt, xc, x0, eps=[eps, eps_2])
         else:
             old_eps = old_out["old_eps"]                  # TypeError on the first step with order == 1, like the reference
@@ -480,7 +487,7 @@ class GaussianDiffusion:
             sample = E.plms_update(cur, coef, tt, xc, x0, eps=old_eps[::-1][:cur])
         if len(old_eps) >= order:
             old_eps.pop(0)
-        return {"sample": sample, "pred_xstart": x0, "old_eps": old_eps}
+        return {"sample": sample, "pred_xstart": x0_orig, "old_eps": old_eps}
 
     def plms_sample_loop(self, model, shape, noise=None, clip_denoised=True, denoised_fn=None, cond_fn=None,
                          model_kwargs=None, device=None, progress=False, skip_timesteps=0, init_image=None,

@@ -147,6 +147,8 @@ int gdx_sampler_update(const gdx_update_args_t* a, void* stream);
  * c[3] sqrt(1 - alpha_bar_prev)) plus c[7] = (t != 0).  idx = t[b] if t != NULL else step_index.
  *   kind 0: out = eps = (c0*x - pred_xstart) / c1                      (_predict_eps_from_xstart :407-411)
  *   kind 6: out = pred_xstart*c2 + c3*eps[0]                           (pseudo improved Euler predictor :1048)
+ *   kind 7: out = pred_xstart under condition_score (:452-472): eps[0] = cond_fn gradient [B,J,1,T],
+ *           eps[1] = device table sqrt(1 - alpha_bar)[num_steps]
  *   kind 1..4: Adams-Bashforth of that order over eps[0] (newest) .. eps[3]   (:1060-1069)
  *   kind 5: eps' = (eps[0] + eps[1]) / 2                               (improved Euler corrector :1050)
  *   kinds 1..5 then: pred' = c0*x - c1*eps';  out = (pred'*c2 + c3*eps')*nz + pred_xstart*(1 - nz)   (:1051-1077) */

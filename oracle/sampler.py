@@ -102,7 +102,8 @@ def predict_xstart(tab, eps, x, t):
 
 
 def plms_step(x0_fn, tab, x, t, order, old_eps):
-    """plms_sample :995-1079.  x0_fn(x, t) -> model x0 prediction after the inpainting blend (p_mean_variance).
+    """plms_sample :995-1079.  x0_fn(x, t) -> x0 prediction after the inpainting blend (p_mean_variance) and, when a
+    cond_fn is used, after condition_score (pass `lambda x, t: cond_xstart(tab, raw_x0_fn(x, t), x, t, grad_fn(x, t))`).
     old_eps: list carried between steps (None on the first step).  Returns (sample, pred_xstart, old_eps)."""
     if not int(order) or not 1 <= order <= 4:
         raise ValueError('order is invalid (should be int from 1-4).')
@@ -205,3 +206,9 @@ def ddim_step_cond(tab, x0, x, t, noise, grad, eta=0.0):
     eps = eps - (1 - ab).sqrt() * grad
     x0c = predict_xstart(tab, eps, x, t)
     return ddim_step(tab, x0c, x, t, noise, eta)
+
+
+def cond_xstart(tab, x0, x, t, grad):
+    """pred_xstart under condition_score (:452-472)."""
+    eps = predict_eps(tab, x0, x, t) - (1 - extract(tab.alphas_cumprod, t)).sqrt() * grad
+    return predict_xstart(tab, eps, x, t)

@@ -317,6 +317,9 @@ def gen_guided_tiny(mods, out):
             with TapeNoise(tape[1:]):
                 d[name] = fn(m, shape, noise=tape[0].clone(), clip_denoised=False, model_kwargs={"y": y}, progress=False,
                              cond_fn=cond_fn_fixture, **kw).numpy()
+        df = make_diffusion(gd, rs, [10])
+        d["plms10_o2_guided"] = df.plms_sample_loop(m, shape, noise=tape[0].clone(), clip_denoised=False, model_kwargs={"y": y},
+                                                    progress=False, cond_fn=cond_fn_fixture).numpy()
         np.savez_compressed(os.path.join(out, f"guided_{arch}_tiny.npz"), **d)
 
 

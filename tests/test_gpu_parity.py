@@ -721,3 +721,17 @@ def test_guided_loops_vs_reference_golden(arch, name, fn, resp, eta):
         kw["eta"] = eta
     r = getattr(_diffusion(resp), fn)(m, tuple(tape[0].shape), **kw)
     assert rel_err(r.cpu(), gg[name]) < LOOP_TOL, name
+
+
+@pytest.mark.parametrize("arch", ["mdm", "mdm_old"])
+def test_plms_guided_loop_vs_reference_golden(arch):
+    """plms_sample_loop with cond_fn (condition_score inside get_model_output, reference :1015-1041)."""
+    g = load_golden(f"loops_{arch}_tiny.npz")
+    gg = load_golden(f"guided_{arch}_tiny.npz")
+    d = dev()
+    m = build_model(arch, TINY, weights_from(g))
+    y = {"seed": torch.from_numpy(g["seed"]).to(d), "mfcc": torch.from_numpy(g["mfcc"]).to(d)}
+    x_T = torch.from_numpy(g["tape"])[0].to(d)
+    r = _diffusion([10]).plms_sample_loop(m, tuple(x_T.shape), noise=x_T.clone(), clip_denoised=False,
+                                          model_kwargs={"y": y}, cond_fn=_cond_fn_fixture)
+    assert rel_err(r.cpu(), gg["plms10_o2_guided"]) < LOOP_TOL

@@ -197,6 +197,26 @@ def test_guided_loops_tiny(arch, name, kind, resp, eta):
 
 
 @pytest.mark.parametrize("arch", ["mdm", "mdm_old"])
+def test_plms_guided_tiny(arch):
+    """plms_sample_loop with cond_fn: condition_score inside get_model_output (reference :1015-1041)."""
+    g = load_golden(f"loops_{arch}_tiny.npz")
+    gg = load_golden(f"guided_{arch}_tiny.npz")
+    p = weights_from(g)
+    cfg = dict(TINY, arch=arch)
+    y = {"seed": torch.from_numpy(g["seed"]), "mfcc": torch.from_numpy(g["mfcc"])}
+    tab, tmap = osch.make_tables("cosine", 1000, [10])
+    mapt = torch.tensor(tmap)
+    img = torch.from_numpy(g["tape"])[0]
+    B = img.shape[0]
+    x0_fn = lambda x, t: osamp.cond_xstart(tab, omf.forward(p, cfg, x, mapt[t], y), x, t, cond_fn_fixture(x, mapt[t]))  # noqa: E731
+    old = None
+    with torch.no_grad():
+        for i in range(tab.num_timesteps - 1, -1, -1):
+            img, _, old = osamp.plms_step(x0_fn, tab, img, torch.tensor([i] * B), 2, old)
+    assert rel_err(img, gg["plms10_o2_guided"]) < 5e-5
+
+
+@pytest.mark.parametrize("arch", ["mdm", "mdm_old"])
 @pytest.mark.parametrize("tag,resp", [("full", [1000]), ("r20", [20])])
 def test_training_losses_forward_half(arch, tag, resp):
     """training_losses' forward values (reference gaussian_diffusion.py:1227-1352): q_sample with per-sample timesteps,
