@@ -807,6 +807,39 @@ extern "C" int gdx_sample_loop(gdx_handle_t h, const gdx_loop_args_t* a, void* s
     return 0;
 }
 
+// MFCC front end (reference data_loaders/gesture/data/dataset.py:81-95).  The caller supplies the tables (built once on the
+// host in fp64, stored fp32) and the workspace; layouts:
+//   dft  [2*nbp][Lp]   rows k < nbins: cos(2 pi k i / nfft), rows nbp + k: -sin(...), zero elsewhere; Lp = frame_len up to 32,
+//                      nbp = nbins up to 64
+//   mel  [64][nbp]     rows j < nfilt: triangular filter j over the nbins power bins, zero elsewhere
+//   work               (numframes + 128) * (Lp + 2*nbp + nbp + 64) + numframes floats
+extern "C" int gdx_mfcc(const float* signal, int64_t n, int32_t frame_len, int32_t frame_step, int32_t numframes,
+                        int32_t nfft, int32_t nfilt, int32_t numcep, float preemph, const float* dft, const float* mel,
+                        const float* dct, const float* lifter, const float* mean, const float* stdv, float* work,
+                        float* out, void* stream) {
+    if (!signal || !dft || !mel || !dct || !lifter || !work || !out) return fail("gdx_mfcc: null argument");
+    if (n <= 0 || frame_len <= 0 || frame_step <= 0 || numframes <= 0 || nfft < frame_len || nfilt <= 0 || nfilt > 64 ||
+        numcep <= 0 || numcep > nfilt)
+        return fail("gdx_mfcc: bad geometry");
+    hipStream_t s = (hipStream_t)stream;
+    hipError_t e = gemm_init();
+    if (e != hipSuccess) return fail(std::string("gemm_init: ") + hipGetErrorString(e));
+    const int nbins = nfft / 2 + 1, Lp = round_up(frame_len, 32), nbp = round_up(nbins, 64), rows = numframes + 128;
+    float* frames = work;
+    float* spec = frames + (size_t)rows * Lp;
+    float* pw = spec + (size_t)rows * 2 * nbp;
+    float* melv = pw + (size_t)rows * nbp;
+    float* energy = melv + (size_t)rows * 64;
+    HIPCHK(launch_mfcc_frames(signal, (long)n, frames, numframes, frame_len, frame_step, Lp, preemph, s));
+    GemmParams p{frames, Lp, dft, Lp, nullptr, nullptr, 0, nullptr, 0, spec, 2 * nbp, numframes, 2 * nbp, Lp, 1, 1};
+    if (gemm(A_ROWS, B_WEIGHT, OUT_ROWS, EPI_BIAS, p, s)) return -1;                       // DFT: [F, L] x [2*nbins, L]^T
+    HIPCHK(launch_mfcc_power(spec, 2 * nbp, nbp, pw, nbp, energy, numframes, nbins, nfft, s));
+    GemmParams q{pw, nbp, mel, nbp, nullptr, nullptr, 0, nullptr, 0, melv, 64, numframes, 64, nbp, 1, 1};
+    if (gemm(A_ROWS, B_WEIGHT, OUT_ROWS, EPI_BIAS, q, s)) return -1;                       // mel energies
+    HIPCHK(launch_mfcc_cepstrum(melv, 64, energy, dct, lifter, mean, stdv, out, numframes, nfilt, numcep, s));
+    return 0;
+}
+
 extern "C" int gdx_set_graph_replay(gdx_handle_t h, int32_t on) {
     if (!h) return fail("gdx_set_graph_replay: null handle");
     h->graph_replay = on != 0;

@@ -110,6 +110,14 @@ hipError_t launch_convert_f32(const _Float16* src, float* dst, int64_t n, hipStr
 bool local_attention_f16_supported(int d, int heads, int window);
 hipError_t launch_local_attention_f16(const _Float16* xseq, const float* cosT, const float* sinT, _Float16* enc16,
                                       float* enc32, int B, int T, int d, int heads, int window, hipStream_t s);
+// MFCC front end pieces (misc.hip); the two transforms in between run on the persistent GEMM (api.hip: gdx_mfcc)
+hipError_t launch_mfcc_frames(const float* x, long n, float* frames, int numframes, int frame_len, int frame_step, int ldf,
+                              float preemph, hipStream_t s);
+hipError_t launch_mfcc_power(const float* spec, int lds, int im_off, float* pw, int ldp, float* energy, int numframes,
+                             int nbins, int nfft, hipStream_t s);
+hipError_t launch_mfcc_cepstrum(const float* mel, int ldm, const float* energy, const float* dct, const float* lift,
+                                const float* mean, const float* stdv, float* out, int numframes, int nfilt, int numcep,
+                                hipStream_t s);
 // out = u + scale[b]*(c - u)
 hipError_t launch_cfg_blend(const float* c, const float* u, const float* scale, float* out, int B,
                             int64_t per_sample, hipStream_t s);

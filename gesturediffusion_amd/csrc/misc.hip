@@ -647,6 +647,95 @@ hipError_t launch_local_attention_f16(const _Float16* xseq, const float* cosT, c
     return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------------------------
+// MFCC front end of y['mfcc'] (reference data_loaders/gesture/data/dataset.py:81-95 -> python_speech_features.mfcc):
+// pre-emphasis + framing, power spectrum (the DFT itself is a GEMM against a cos / -sin table, api.hip), log mel
+// energies (GEMM against the filterbank), DCT-II + lifter + log-energy + z-score.
+//   frames[f][i] = s[f*step + i] with s[0] = x[0], s[n] = x[n] - preemph * x[n-1], zero past the signal; row stride ldf
+__global__ void mfcc_frames_kernel(const float* __restrict__ x, long n, float* __restrict__ frames, int numframes,
+                                   int frame_len, int frame_step, int ldf, float preemph) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)numframes * ldf) return;
+    const int f = i / ldf, c = i % ldf;
+    float v = 0.0f;
+    const long idx = (long)f * frame_step + c;
+    if (c < frame_len && idx < n) v = idx == 0 ? x[0] : x[idx] - preemph * x[idx - 1];
+    frames[i] = v;
+}
+
+// pw[f][k] = (re^2 + im^2) / nfft for k < nbins (zero in the padding columns); energy[f] = sum_k pw[f][k] (0 -> eps)
+// spec rows: [re(0..nbins-1) | pad][im(0..nbins-1) | pad], im block at column im_off.  One block per frame.
+__global__ __launch_bounds__(256) void mfcc_power_kernel(const float* __restrict__ spec, int lds, int im_off,
+                                                         float* __restrict__ pw, int ldp, float* __restrict__ energy,
+                                                         int nbins, float inv_nfft) {
+    __shared__ float red[256];
+    const int f = blockIdx.x, tid = threadIdx.x;
+    const float* sp = spec + (long)f * lds;
+    float e = 0.0f;
+    for (int k = tid; k < ldp; k += 256) {
+        float p = 0.0f;
+        if (k < nbins) {
+            const float re = sp[k], im = sp[im_off + k];
+            p = (re * re + im * im) * inv_nfft;
+        }
+        pw[(long)f * ldp + k] = p;
+        e += p;
+    }
+    red[tid] = e;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (tid < o) red[tid] += red[tid + o];
+        __syncthreads();
+    }
+    if (tid == 0) energy[f] = red[0] == 0.0f ? 2.220446049250313e-16f : red[0];
+}
+
+// out[f][c] = ((lift[c] * sum_j dct[c][j] * log(mel[f][j])) [c == 0: log(energy[f])] - mean[c]) / std[c]
+__global__ void mfcc_cepstrum_kernel(const float* __restrict__ mel, int ldm, const float* __restrict__ energy,
+                                     const float* __restrict__ dct, const float* __restrict__ lift,
+                                     const float* __restrict__ mean, const float* __restrict__ stdv,
+                                     float* __restrict__ out, int numframes, int nfilt, int numcep) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= numframes * numcep) return;
+    const int f = i / numcep, c = i % numcep;
+    float v;
+    if (c == 0) {
+        v = logf(energy[f]);
+    } else {
+        float acc = 0.0f;
+        for (int j = 0; j < nfilt; ++j) {
+            float m = mel[(long)f * ldm + j];
+            m = m == 0.0f ? 2.220446049250313e-16f : m;
+            acc = fmaf(dct[c * nfilt + j], logf(m), acc);
+        }
+        v = lift[c] * acc;
+    }
+    if (mean) v = (v - mean[c]) / stdv[c];
+    out[i] = v;
+}
+
+hipError_t launch_mfcc_frames(const float* x, long n, float* frames, int numframes, int frame_len, int frame_step, int ldf,
+                              float preemph, hipStream_t s) {
+    const long total = (long)numframes * ldf;
+    hipLaunchKernelGGL(mfcc_frames_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x, n, frames, numframes,
+                       frame_len, frame_step, ldf, preemph);
+    return hipGetLastError();
+}
+hipError_t launch_mfcc_power(const float* spec, int lds, int im_off, float* pw, int ldp, float* energy, int numframes,
+                             int nbins, int nfft, hipStream_t s) {
+    hipLaunchKernelGGL(mfcc_power_kernel, dim3(numframes), dim3(256), 0, s, spec, lds, im_off, pw, ldp, energy, nbins,
+                       1.0f / (float)nfft);
+    return hipGetLastError();
+}
+hipError_t launch_mfcc_cepstrum(const float* mel, int ldm, const float* energy, const float* dct, const float* lift,
+                                const float* mean, const float* stdv, float* out, int numframes, int nfilt, int numcep,
+                                hipStream_t s) {
+    const int total = numframes * numcep;
+    hipLaunchKernelGGL(mfcc_cepstrum_kernel, dim3((total + 255) / 256), dim3(256), 0, s, mel, ldm, energy, dct, lift, mean,
+                       stdv, out, numframes, nfilt, numcep);
+    return hipGetLastError();
+}
+
 __global__ void convert_f16_kernel(const float* __restrict__ src, _Float16* __restrict__ dst, int64_t n) {
     const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
     if (i + 3 < n) {

@@ -66,8 +66,19 @@ def main(argv=None):
         mean, std = stat_rng.normal(size=J), stat_rng.uniform(0.5, 2.0, size=J)
     sample_fn = diffusion.p_sample_loop if args.sampler == "p" else diffusion.ddim_sample_loop
     sample_out = None
+    extractor = None
+    if args.synthetic_audio:
+        # the reference's audio path (dataset.py:81-95) at its GENEA settings: 22 050 Hz, 30 fps, one MFCC vector per frame
+        from ..data_loaders.mfcc import MfccExtractor
+        stat = np.random.default_rng(args.seed + 1)
+        extractor = MfccExtractor(device, sr=22050, fps=30, mfcc_mean=stat.normal(size=MFCC_DIM),
+                                  mfcc_std=stat.uniform(0.5, 2.0, size=MFCC_DIM))
     for chunk in range(args.chunks):
-        mfcc = torch.randn(num_samples, MFCC_DIM, 1, T, generator=g)[lo:hi].to(device)
+        if extractor is not None:
+            audio = 0.1 * torch.randn(num_samples, T * 735, generator=g)[lo:hi].to(device)
+            mfcc = torch.stack([extractor(a)[:T].t() for a in audio]).unsqueeze(2).contiguous()     # [nb, 26, 1, T]
+        else:
+            mfcc = torch.randn(num_samples, MFCC_DIM, 1, T, generator=g)[lo:hi].to(device)
         y = {"mfcc": mfcc, "seed": seed_all[lo:hi].to(device) if chunk == 0 else sample_out[..., -args.seed_poses:]}
         if args.guidance_param != 1:
             y["scale"] = torch.ones(nb, device=device) * args.guidance_param

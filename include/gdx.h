@@ -191,6 +191,19 @@ int gdx_randn(float* out, int32_t batch, int64_t per_sample, uint64_t philox_see
 int gdx_postprocess(const float* x, const double* mean, const double* std, float* pos, float* rot,
                     int32_t batch, int32_t n_joints, int32_t frames, void* stream);
 
+/* ---- conditioning features ---------------------------------------------- */
+/* MFCC vectors of one audio chunk, replacing the CPU call at data_loaders/gesture/data/dataset.py:81-95
+ * (python_speech_features.mfcc(signal, winlen=0.06, winstep=1/fps, samplerate=sr, numcep=27, nfft=5000) and the z-score):
+ * pre-emphasis + rectangular framing, power spectrum by a DFT-as-GEMM on the fp32 MFMA kernel, mel filterbank (GEMM),
+ * log, DCT-II (ortho), sinusoidal lifter, log frame energy in coefficient 0, (m - mean) / std.
+ * signal [n] fp32 (device); tables and workspace as laid out at the definition (csrc/api.hip); mean / std [numcep] or
+ * NULL; out [numframes][numcep] fp32.  The package is absent from this image: parity with it is UNPINNED
+ * (oracle/mfcc.py restates its published algorithm). */
+int gdx_mfcc(const float* signal, int64_t n, int32_t frame_len, int32_t frame_step, int32_t numframes,
+             int32_t nfft, int32_t nfilt, int32_t numcep, float preemph, const float* dft, const float* mel,
+             const float* dct, const float* lifter, const float* mean, const float* std, float* work,
+             float* out, void* stream);
+
 /* ---- whole loop ------------------------------------------------------------------------ */
 /* replaces p_sample_loop / ddim_sample_loop (gaussian_diffusion.py:598-661, 879-926) in the
  * configured mode (START_X, FIXED_SMALL, clip_denoised=False): iterates index = first_index

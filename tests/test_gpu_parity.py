@@ -368,6 +368,7 @@ def test_error_behaviour_matches_reference(golden_dir):
 @pytest.mark.parametrize("extra", [["--arch_version", "mdm_old", "--num_frames", "23", "--guidance_param", "1"],
                                    ["--arch_version", "mdm", "--num_frames", "20", "--compute_dtype", "fp16"],
                                    ["--arch_version", "mdm", "--num_frames", "20", "--synthetic_njoints", "48"],
+                                   ["--arch_version", "mdm_old", "--num_frames", "31", "--synthetic_audio"],
                                    ["--arch_version", "mdm", "--num_frames", "20", "--rng", "philox"],
                                    ["--arch_version", "mdm", "--num_frames", "20", "--sampler", "ddim", "--timestep_respacing", "ddim10"]])
 def test_generate_cli_synthetic(tmp_path, extra):
@@ -735,3 +736,21 @@ def test_plms_guided_loop_vs_reference_golden(arch):
     r = _diffusion([10]).plms_sample_loop(m, tuple(x_T.shape), noise=x_T.clone(), clip_denoised=False,
                                           model_kwargs={"y": y}, cond_fn=_cond_fn_fixture)
     assert rel_err(r.cpu(), gg["plms10_o2_guided"]) < LOOP_TOL
+
+
+@pytest.mark.parametrize("n", [88200, 44100 + 17, 1000])
+def test_mfcc_front_end_vs_restated_package(n):
+    """gdx_mfcc against oracle/mfcc.py.  PARITY UNPINNED with respect to the reference: the oracle restates
+    python_speech_features 0.6 (absent from this image, no fixtures in the reference); 120-frame chunk, a ragged chunk
+    and a chunk shorter than one frame."""
+    from gesturediffusion_amd.data_loaders.mfcc import MfccExtractor
+    from oracle import mfcc as om
+    rng = np.random.default_rng(n)
+    t = np.arange(n) / 22050.0
+    sig = (0.3 * np.sin(2 * np.pi * 220 * t) + 0.1 * np.sin(2 * np.pi * 1870 * t) + 0.05 * rng.normal(size=n)).astype(np.float32)
+    mean, std = rng.normal(size=26), rng.uniform(0.5, 3.0, size=26)
+    want = om.genea_mfcc(sig.astype(np.float64), 22050, 30, mean, std)
+    ex = MfccExtractor(dev(), mfcc_mean=mean, mfcc_std=std)
+    got = ex(torch.from_numpy(sig).to(dev()))
+    assert tuple(got.shape) == want.shape == (ex.num_frames(n), 26)
+    assert rel_err(got.cpu(), want) < 2e-4
