@@ -469,6 +469,7 @@ __global__ __launch_bounds__(512, 1) void gemmh8_kernel(const GemmHParams p, con
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     int ks = 0, stage = 0, tile_i = 0, wst = NST - 1;
+    bool skip_wait = false;
     rd(fa0, fw0, 0);
     unsigned long long t0 = 0, r0 = 0;
     if (dbg) { t0 = __builtin_amdgcn_s_memtime(); r0 = __builtin_amdgcn_s_memrealtime(); }
@@ -480,7 +481,16 @@ __global__ __launch_bounds__(512, 1) void gemmh8_kernel(const GemmHParams p, con
             rd(fa1, fw1, nstage);
             mm(fa0, fw0);
             interleave();
-            step_sync();
+            if (skip_wait) {                                      // first step of a tile: see the tile-end comment
+                skip_wait = false;
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_waitcnt(0xc07f);
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+            } else {
+                step_sync();
+            }
             stage = nstage;
             nstage = stage == NST - 1 ? 0 : stage + 1;
             issue(wst);
@@ -490,13 +500,27 @@ __global__ __launch_bounds__(512, 1) void gemmh8_kernel(const GemmHParams p, con
             interleave();
             ks += 2;
             if (ks == nk) {
+                // Tile end.  The epilogue's global stores share vmcnt with the DMA, and a counted wait behind them would
+                // stall every wave (through the barrier) until the stores retire.  So drain the DMA queue BEFORE the
+                // stores are issued (slabs <= g+3 landed: one slab's latency, once per tile), and let the next step
+                // skip its wait (it needs slab g+3 only).  The step after that waits for "<= 4 outstanding" again:
+                // the 4 pieces of the youngest slab are behind the slab it needs, so the count is only reached once
+                // that slab has landed, whatever order the stores retire in.
                 ks = 0;
                 const int tile = lid + tile_i * G;
                 ++tile_i;
+                __builtin_amdgcn_sched_barrier(0);
+                wait_vm_h<0>();
+                __builtin_amdgcn_s_waitcnt(0xc07f);
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
                 wave_epilogue<MB, NBW>(p, acc, bias_lds, (tile / ntn) * BM + wr * WM, (tile % ntn) * BN + wc * WN, l15, lq);
                 tile_base(tile_i + 1, a_nxt, w_nxt);              // the DMA stream is already inside tile tile_i
+                skip_wait = true;
+            } else {
+                step_sync();
             }
-            step_sync();
             stage = nstage;
         }
     }

@@ -428,6 +428,33 @@ def gen_negative(mods, out):
             f.write(f"{k}={v}\n")
 
 
+def collate_inputs(seed=5):
+    """Ragged GENEA-style items (`data_loaders/gesture/data/dataset.py` __getitem__ order: motion [len, J], text,
+    length, audio [len * 735], mfcc [len, 26], seed poses [n_seed, J]); shared by the generator and the tests."""
+    rng = np.random.default_rng(seed)
+    items = []
+    for n in (12, 7, 12, 9):
+        items.append((rng.normal(size=(n, 6)), f"take{n}", n, rng.normal(size=n * 5).astype(np.float32),
+                      rng.normal(size=(n, 26)), rng.normal(size=(4, 6))))
+    return items
+
+
+def gen_collate(mods, out):
+    """`gg_collate` / `collate` / `collate_tensors` / `lengths_to_mask` of `data_loaders/tensors.py:3-66`."""
+    import importlib
+    ten = importlib.import_module("data_loaders.tensors")
+    items = collate_inputs()
+    # audio and mfcc are concatenated along dim 0 (`tensors.py:43-49`), so their trailing sizes must agree: crop to the shortest
+    nmin = min(x[2] for x in items)
+    items = [(x[0], x[1], x[2], x[3][:nmin * 5], x[4][:nmin], x[5]) for x in items]
+    motion, cond = ten.gg_collate(items)
+    y = cond["y"]
+    ragged = ten.collate_tensors([torch.ones(2, 3), torch.ones(1, 5) * 2, torch.ones(3, 1) * 3])
+    np.savez(os.path.join(out, "collate.npz"), motion=motion.numpy(), mask=y["mask"].numpy(), lengths=y["lengths"].numpy(),
+             mfcc=y["mfcc"].numpy(), audio=y["audio"].numpy(), seed=y["seed"].numpy(), text=np.array(y["text"]),
+             ragged=ragged.numpy(), len_mask=ten.lengths_to_mask(torch.tensor([0, 3, 5]), 5).numpy())
+
+
 def gen_state_dict_keys(mods, out):
     """State-dict key -> shape listing of the reference modules (drop-in contract)."""
     with open(os.path.join(out, "state_dict_keys.txt"), "w") as f:
@@ -442,13 +469,13 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--ref", default="/root/reference")
     ap.add_argument("--out", default=os.path.join(REPO, "tests", "golden"))
-    ap.add_argument("--only", default="", help="comma-separated subset: schedule,forward,loops,plms,losses,guided,real,negative,keys")
+    ap.add_argument("--only", default="", help="comma-separated subset: schedule,forward,loops,plms,losses,guided,collate,real,negative,keys")
     args = ap.parse_args()
     os.makedirs(args.out, exist_ok=True)
     torch.set_num_threads(8)
     mods = import_reference(args.ref)
     gens = {"schedule": gen_schedule, "forward": gen_forward_tiny, "loops": gen_loops_tiny, "plms": gen_plms_tiny, "losses": gen_losses_tiny, "guided": gen_guided_tiny,
-            "real": gen_real_shapes, "negative": gen_negative, "keys": gen_state_dict_keys}
+            "collate": gen_collate, "real": gen_real_shapes, "negative": gen_negative, "keys": gen_state_dict_keys}
     for name in (args.only.split(",") if args.only else gens):
         gens[name](mods, args.out)
     for f in sorted(os.listdir(args.out)):
