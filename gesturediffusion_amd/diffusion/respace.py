@@ -12,47 +12,41 @@ from .gaussian_diffusion import GaussianDiffusion
 
 
 def space_timesteps(num_timesteps, section_counts):
-    if isinstance(section_counts, str):
-        if section_counts.startswith("ddim"):
-            desired_count = int(section_counts[len("ddim"):])
-            for i in range(1, num_timesteps):
-                if len(range(0, num_timesteps, i)) == desired_count:
-                    return set(range(0, num_timesteps, i))
+    """Set of original timesteps to keep.  "ddimN": the first integer stride that yields exactly N steps; otherwise
+    a list (or comma-separated string) of per-section counts, each section sampled at an even fractional stride whose
+    running position is accumulated in floating point and rounded (the accumulation order decides ties)."""
+    if isinstance(section_counts, str) and section_counts.startswith("ddim"):
+        want = int(section_counts[4:])
+        stride = next((s for s in range(1, num_timesteps) if -(-num_timesteps // s) == want), None)
+        if stride is None:
             raise ValueError(f"cannot create exactly {num_timesteps} steps with an integer stride")
-        section_counts = [int(x) for x in section_counts.split(",")]
-    size_per = num_timesteps // len(section_counts)
-    extra = num_timesteps % len(section_counts)
-    start_idx = 0
-    all_steps = []
-    for i, section_count in enumerate(section_counts):
-        size = size_per + (1 if i < extra else 0)
-        if size < section_count:
-            raise ValueError(f"cannot divide section of {size} steps into {section_count}")
-        frac_stride = 1 if section_count <= 1 else (size - 1) / (section_count - 1)
-        cur_idx = 0.0
-        taken_steps = []
-        for _ in range(section_count):
-            taken_steps.append(start_idx + round(cur_idx))
-            cur_idx += frac_stride
-        all_steps += taken_steps
-        start_idx += size
-    return set(all_steps)
+        return set(range(0, num_timesteps, stride))
+    counts = [int(c) for c in section_counts.split(",")] if isinstance(section_counts, str) else list(section_counts)
+    base, extra = divmod(num_timesteps, len(counts))
+    kept, first = set(), 0
+    for k, n in enumerate(counts):
+        size = base + (1 if k < extra else 0)
+        if size < n:
+            raise ValueError(f"cannot divide section of {size} steps into {n}")
+        step = (size - 1) / (n - 1) if n > 1 else 1
+        pos = 0.0
+        for _ in range(n):
+            kept.add(first + round(pos))
+            pos += step
+        first += size
+    return kept
 
 
 class SpacedDiffusion(GaussianDiffusion):
+    """A diffusion process over the kept subset of a base process's steps: beta_k = 1 - abar[t_k] / abar[t_{k-1}]."""
+
     def __init__(self, use_timesteps, **kwargs):
+        full = GaussianDiffusion(**kwargs)
+        self.original_num_steps = full.num_timesteps
         self.use_timesteps = set(use_timesteps)
-        self.timestep_map = []
-        self.original_num_steps = len(kwargs["betas"])
-        base_diffusion = GaussianDiffusion(**kwargs)
-        last_alpha_cumprod = 1.0
-        new_betas = []
-        for i, alpha_cumprod in enumerate(base_diffusion.alphas_cumprod):
-            if i in self.use_timesteps:
-                new_betas.append(1 - alpha_cumprod / last_alpha_cumprod)
-                last_alpha_cumprod = alpha_cumprod
-                self.timestep_map.append(i)
-        kwargs["betas"] = np.array(new_betas)
+        self.timestep_map = sorted(t for t in self.use_timesteps if 0 <= t < full.num_timesteps)
+        abar = full.alphas_cumprod[self.timestep_map]
+        kwargs["betas"] = 1 - abar / np.concatenate(([1.0], abar[:-1]))
         super().__init__(**kwargs)
 
     def _wrap_model(self, model):
@@ -84,14 +78,17 @@ class _WrappedModel:
         self.original_num_steps = original_num_steps
 
     def __call__(self, x, ts, **kwargs):
+        return self.model(x, self.map_timesteps(ts), **kwargs)
+
+    def map_timesteps(self, ts):
+        """Respaced index -> original timestep, looked up on `ts`'s device (table cached per device and dtype)."""
         key = (id(self.timestep_map), len(self.timestep_map), str(ts.device), ts.dtype)
-        map_tensor = _MAP_CACHE.get(key)
-        if map_tensor is None:
-            map_tensor = th.tensor(self.timestep_map, device=ts.device, dtype=ts.dtype)
+        table = _MAP_CACHE.get(key)
+        if table is None:
             if len(_MAP_CACHE) > 64:
                 _MAP_CACHE.clear()
-            _MAP_CACHE[key] = map_tensor
-        new_ts = map_tensor[ts]
+            table = _MAP_CACHE[key] = th.tensor(self.timestep_map, device=ts.device, dtype=ts.dtype)
+        mapped = table[ts]
         if self.rescale_timesteps:
-            new_ts = new_ts.float() * (1000.0 / self.original_num_steps)
-        return self.model(x, new_ts, **kwargs)
+            mapped = mapped.float() * (1000.0 / self.original_num_steps)
+        return mapped

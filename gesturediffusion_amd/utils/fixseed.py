@@ -6,7 +6,7 @@ import torch
 
 
 def fixseed(seed):
-    torch.backends.cudnn.benchmark = False
-    random.seed(seed)
-    np.random.seed(seed)
-    torch.manual_seed(seed)
+    """Seed Python's, NumPy's and torch's global generators (the loops draw x_T and z from torch's when rng="torch")."""
+    for seeder in (random.seed, np.random.seed, torch.manual_seed):
+        seeder(seed)
+    torch.backends.cudnn.benchmark = False                # MIOpen autotuning off, as the reference sets it
