@@ -517,8 +517,11 @@ static int forward_core(gdx_model* h, const float* x, const float* temb, int tst
         const Layer& ly = h->layers[l];
         p = GemmParams{h->xa, d, ly.qkv.w, ly.qkv.kpad, ly.qkv.bias, nullptr, 0, nullptr, 0, h->qkv, 3 * d, N, 3 * d, d, T, B};
         if (gemm(A_ROWS, B_WEIGHT, OUT_ROWS, EPI_BIAS, p, s)) return -1;
-        static const bool attn_v1 = getenv("GDX_ATTN_V1") != nullptr;   // A/B switch for measurements
-        if (!attn_v1 && attention2_supported(S, h->H, d))
+        static const bool attn_v1 = getenv("GDX_ATTN_V1") != nullptr;   // A/B switches for measurements
+        static const bool attn_v2 = getenv("GDX_ATTN_V2") != nullptr;
+        if (!attn_v1 && !attn_v2 && attention3_supported(S, h->H, d))
+            HIPCHK(launch_attention3(h->qkv, h->ctx, Beff, S, h->H, d, s));
+        else if (!attn_v1 && attention2_supported(S, h->H, d))
             HIPCHK(launch_attention2(h->qkv, h->ctx, Beff, S, h->H, d, s));
         else
             HIPCHK(launch_attention(h->qkv, h->ctx, Beff, S, h->H, d, s));
@@ -1023,6 +1026,38 @@ extern "C" int gdx_attention_f16(const float* qkv, float* ctx, int32_t B, int32_
     return rc;
 }
 
+// fp32 SDPA core on a caller's [B*S][3d] buffer (test entry point).  The kernels read whole K/V tiles past the last
+// sample, so the call works on a scratch copy with 128 zero rows behind it, like the workspace of gdx_prepare.
+extern "C" int gdx_attention_f32(const float* qkv, float* ctx, int32_t B, int32_t S, int32_t H, int32_t d, int32_t version,
+                                 void* stream) {
+    if (!qkv || !ctx || B <= 0 || S <= 0 || H <= 0 || d <= 0 || d % H) return fail("gdx_attention_f32: bad argument");
+    const int hd = d / H;
+    if (hd != 32 && hd != 64 && hd != 128 && hd != 256) return fail("gdx_attention_f32: head_dim must be 32, 64, 128 or 256");
+    if ((version == 2 && !attention2_supported(S, H, d)) || (version == 3 && !attention3_supported(S, H, d)))
+        return fail("gdx_attention_f32: shape not supported by the requested kernel");
+    hipStream_t s = (hipStream_t)stream;
+    const size_t rows = (size_t)B * S, prow = rows + 128;
+    float *q = nullptr, *c = nullptr;
+    std::vector<void*> pool;
+    int rc = 0;
+    if (dev_alloc(pool, (void**)&q, sizeof(float) * prow * 3 * d) || dev_alloc(pool, (void**)&c, sizeof(float) * prow * d)) rc = -1;
+    if (!rc && (hipMemsetAsync(q, 0, sizeof(float) * prow * 3 * d, s) != hipSuccess ||
+                hipMemcpyAsync(q, qkv, sizeof(float) * rows * 3 * d, hipMemcpyDeviceToDevice, s) != hipSuccess))
+        rc = fail("gdx_attention_f32: staging failed");
+    if (!rc) {
+        hipError_t e;
+        if (version == 3 || (version == 0 && attention3_supported(S, H, d))) e = launch_attention3(q, c, B, S, H, d, s);
+        else if (version == 2 || (version == 0 && attention2_supported(S, H, d))) e = launch_attention2(q, c, B, S, H, d, s);
+        else e = launch_attention(q, c, B, S, H, d, s);
+        if (e != hipSuccess) rc = fail(std::string("gdx_attention_f32: ") + hipGetErrorString(e));
+    }
+    if (!rc && hipMemcpyAsync(ctx, c, sizeof(float) * rows * d, hipMemcpyDeviceToDevice, s) != hipSuccess)
+        rc = fail("gdx_attention_f32: copy-out failed");
+    (void)hipStreamSynchronize(s);
+    free_pool(pool);
+    return rc;
+}
+
 extern "C" int gdx_bench_gemm_f16(int32_t M, int32_t N, int32_t K, int32_t gelu, int32_t iters, float* avg_us, void* stream) {
     if (!avg_us || M <= 0 || N <= 0 || K <= 0 || K % 64 || N % 64 || iters <= 0) return fail("gdx_bench_gemm_f16: bad argument");
     hipStream_t s = (hipStream_t)stream;
@@ -1106,6 +1141,7 @@ extern "C" int gdx_bench_attention(int32_t B, int32_t S, int32_t H, int32_t d, i
     }
     auto run = [&]() -> hipError_t {
         if (version == 3) return launch_attentionh(qkv16, ctx16, B, S, H, d, (long)rows, s);
+        if (version == 4 && attention3_supported(S, H, d)) return launch_attention3(qkv, ctx, B, S, H, d, s);
         if (version == 2 && attention2_supported(S, H, d)) return launch_attention2(qkv, ctx, B, S, H, d, s);
         return launch_attention(qkv, ctx, B, S, H, d, s);
     };

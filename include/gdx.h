@@ -265,6 +265,12 @@ int gdx_linear_f16(const float* A, const float* W, const float* bias, float* C32
  * (csrc/attentionh.hip): qkv [B*S][3d] and ctx [B*S][d] are fp32 device arrays converted to / from
  * fp16 by the call.  head_dim = d / H in {32, 64, 128, 256}.  Synchronises the stream. */
 int gdx_attention_f16(const float* qkv, float* ctx, int32_t B, int32_t S, int32_t H, int32_t d, void* stream);
+/* ctx = softmax(Q K^T / sqrt(hd)) V per (sample, head) through the fp32 attention kernels: the SDPA inside
+ * nn.MultiheadAttention of the encoder layers (model/mdm.py:90-96).  qkv [B*S][3d], ctx [B*S][d] fp32 device arrays.
+ * version 0 = the choice gdx_forward makes, 1 = 32x32-block kernel (attention.hip), 2 = attention2.hip,
+ * 3 = attention3.hip.  Test entry point: works on a padded scratch copy and synchronises the stream. */
+int gdx_attention_f32(const float* qkv, float* ctx, int32_t B, int32_t S, int32_t H, int32_t d, int32_t version,
+                      void* stream);
 /* Time `iters` launches of the fp16 GEMM on scratch operands filled with N(0,1). */
 int gdx_bench_gemm_f16(int32_t M, int32_t N, int32_t K, int32_t gelu, int32_t iters, float* avg_us,
                        void* stream);

@@ -446,6 +446,32 @@ def test_fp16_attention_vs_torch(B, S, H, dm):
     assert rel_err(ctx.cpu().double(), ref.cpu()) < 2e-3
 
 
+@pytest.mark.parametrize("version", [1, 2, 3])
+@pytest.mark.parametrize("B,S,H,dm", [(3, 197, 4, 512), (2, 201, 4, 512), (2, 61, 4, 512), (2, 65, 4, 512), (2, 129, 4, 512),
+                                      (1, 256, 4, 512), (2, 241, 4, 512), (3, 1, 4, 512), (2, 16, 4, 512), (2, 197, 8, 512),
+                                      (2, 81, 2, 128), (66, 197, 4, 512)])
+def test_fp32_attention_vs_torch(B, S, H, dm, version):
+    """The three fp32 SDPA kernels (csrc/attention.hip, attention2.hip, attention3.hip) against fp64 softmax attention:
+    the BASELINE sequence lengths (197, 201, 61), every 4k + 1 block count that makes attention3 share the last query
+    block out over four waves (65, 129, 197), full 16 blocks, one token, head_dim 64 and 128, more workgroups than CUs."""
+    import ctypes as C
+    from gesturediffusion_amd import _lib
+    lib = _lib.load()
+    d = dev()
+    hd = dm // H
+    g = torch.Generator(device=d).manual_seed(S + version)
+    qkv = torch.randn(B * S, 3 * dm, device=d, generator=g)
+    qkv[:, :dm] *= 3.0                                   # peaked rows: exercises the deferred-max rescale
+    ctx = torch.full((B * S, dm), float("nan"), device=d)
+    s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    _lib.check(lib.gdx_attention_f32(C.c_void_p(qkv.data_ptr()), C.c_void_p(ctx.data_ptr()), B, S, H, dm, version, s), lib)
+    r = qkv.double().view(B, S, 3, H, hd)
+    q, k, v = (r[:, :, i].permute(0, 2, 1, 3) for i in range(3))
+    p = torch.softmax(q @ k.transpose(-1, -2) / hd ** 0.5, dim=-1)
+    ref = (p @ v).permute(0, 2, 1, 3).reshape(B * S, dm)
+    assert rel_err(ctx.cpu().double(), ref.cpu()) < 2e-6
+
+
 @pytest.mark.parametrize("name,arch,J,dm", [("c1_v2", "mdm", 150, 512), ("c2_v1", "mdm_old", 263, 512),
                                             ("c5_v2", "mdm", 498, 1024)])
 def test_fp16_mode_real_shapes_vs_reference_golden(name, arch, J, dm):
