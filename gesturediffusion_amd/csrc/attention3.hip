@@ -84,7 +84,6 @@ __global__ __launch_bounds__(512, 1) void attention3_kernel(const float* __restr
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcV, (lds_ptr3_t)(sb + K_BYTES + i * 8192), 16, voffV, so + i * 8 * RPP * ld4, 0, 0);
         asm volatile("" ::: "memory");
     };
-    issue(0, 0);
 
     // ---- Q^T fragments (scaled): qf[slot][kk] = Q[query][16kk + 4lq .. +3], query = 16*block(slot) + l15
     auto slot_block = [&](int slot) { return (has_r && slot == n_own) ? nqb - 1 : wave + 8 * slot; };
@@ -109,6 +108,10 @@ __global__ __launch_bounds__(512, 1) void attention3_kernel(const float* __restr
         m_run[qi] = -INFINITY;
         l_run[qi] = 0.0f;
     }
+    // the Q loads go first: an LDS-DMA instruction blocks its wave while the CU's queue is full (stamps: 7 k cycles for
+    // the second wave of a SIMD at start-up, when all 256 workgroups fetch at once), ordinary loads do not
+    asm volatile("" ::: "memory");
+    issue(0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // tile 0 (this wave's pieces) and Q
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
