@@ -8,7 +8,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libgdx.so")
+# GDX_LIBGDX: another build of the same library (A/B measurements of one kernel on one box); there is still no fallback
+LIB_PATH = os.environ.get("GDX_LIBGDX") or os.path.join(_HERE, "csrc", "libgdx.so")
 
 GDX_ARCH_MDM_OLD, GDX_ARCH_MDM = 1, 2
 GDX_COND, GDX_UNCOND, GDX_CFG = 0, 1, 2

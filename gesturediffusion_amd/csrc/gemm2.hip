@@ -213,7 +213,7 @@ __global__ __launch_bounds__(512, 1) void gemm4_kernel(const GemmParams p, const
             for (int i = 0; i < MB; ++i)
 #pragma unroll
                 for (int j = 0; j < NBW; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i][e], fb[j][e], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fb[j][e], fa[i][e], acc[i][j], 0, 0, 0);   // swapped: D = W A^T
     };
 
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // slabs 0 and 1 landed (loaders waited)
@@ -244,19 +244,21 @@ __global__ __launch_bounds__(512, 1) void gemm4_kernel(const GemmParams p, const
         interleave();
         if (++ks == nk) {
             ks = 0;
-            // ---- epilogue straight from the accumulators (col = lane&15, row = 4*(lane>>4) + reg); whole tiles
-            //      are stored (the caller pads C by >= 128 rows), so exactly NSTORE store instructions issue
+            // ---- epilogue straight from the accumulators.  The MFMA runs swapped (weight fragment = A operand), so a
+            //      lane holds ONE output row (lane & 15) and 4 consecutive columns (4 * (lane >> 4) + reg) per block:
+            //      one 16-byte store per block instead of four 4-byte ones, bias / R / V as float4.  Whole tiles are
+            //      stored (the caller pads C by >= 128 rows), so exactly MB * NBW store instructions issue.
             const int tile = lid + tile_i * G;
             ++tile_i;
             const int m0 = (tile / ntn) * BM, n0 = (tile % ntn) * BN;
             const bool rowmap = omode == OUT_TOKROWS;
+            const int nl = n0 + wave * WN + 4 * lq;                 // this lane's first column of block j = 0
             if (!rowmap && !p.R && !p.V) {
-                // plain epilogue (the four encoder GEMMs): row pointers are base + constant * ldc
+                // plain epilogue (the four encoder GEMMs)
+                float* cp = p.C + (long)(m0 + l15) * p.ldc + nl;
 #pragma unroll
                 for (int j = 0; j < NBW; ++j) {
-                    const int n = n0 + wave * WN + j * 16 + l15;
-                    const float bv = bias_lds[n];
-                    float* cp = p.C + (long)(m0 + 4 * lq) * p.ldc + n;
+                    const f32x4 bv = *reinterpret_cast<const f32x4*>(&bias_lds[nl + j * 16]);
 #pragma unroll
                     for (int i = 0; i < MB; ++i) {
                         f32x4 v = acc[i][j] + bv;
@@ -264,8 +266,7 @@ __global__ __launch_bounds__(512, 1) void gemm4_kernel(const GemmParams p, const
                             const f32x2 lo = gelu_fast2(f32x2{v[0], v[1]}), hi = gelu_fast2(f32x2{v[2], v[3]});
                             v = f32x4{lo.x, lo.y, hi.x, hi.y};
                         }
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) cp[(long)(i * 16 + e) * p.ldc] = v[e];
+                        *reinterpret_cast<f32x4*>(cp + (long)(i * 16) * p.ldc + j * 16) = v;
                         acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
                     }
                 }
@@ -277,52 +278,41 @@ __global__ __launch_bounds__(512, 1) void gemm4_kernel(const GemmParams p, const
                 // utilisation 0.29, profiles/r01e_pmc_mfma_util_fp32_*).
                 const bool need_b = rowmap || p.V != nullptr;
                 f32x4 add[MB][NBW];
-                long rows[MB][4];
+                long rows[MB];
 #pragma unroll
                 for (int i = 0; i < MB; ++i) {
-                    // sample index of this lane's 4 rows: one division per 16-row block, then at most one sample
-                    // boundary inside it when T >= 16
-                    int bs[4] = {0, 0, 0, 0};
+                    // sample index of this lane's row: one division per 16-row block, then at most one sample boundary
+                    // inside it when T >= 16
+                    int bs = 0;
                     if (need_b) {
                         const int mb0 = m0 + i * 16;
-                        const int bb0 = mb0 / p.T, tt0 = mb0 - bb0 * p.T;
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            const int r = tt0 + 4 * lq + e;
-                            bs[e] = p.T >= 16 ? bb0 + (r >= p.T ? 1 : 0) : bb0 + r / p.T;
-                        }
+                        const int bb0 = mb0 / p.T, r = mb0 - bb0 * p.T + l15;
+                        bs = p.T >= 16 ? bb0 + (r >= p.T ? 1 : 0) : bb0 + r / p.T;
                     }
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const int m = m0 + i * 16 + 4 * lq + e;
-                        rows[i][e] = rowmap ? (long)m + bs[e] + 1 : (long)m;
-                    }
+                    const int m = m0 + i * 16 + l15;
+                    rows[i] = rowmap ? (long)m + bs + 1 : (long)m;
 #pragma unroll
                     for (int j = 0; j < NBW; ++j) {
-                        const int n = n0 + wave * WN + j * 16 + l15;
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            float a = 0.0f;
-                            if (p.R) a = p.R[rows[i][e] * p.ldr + n];
-                            if (p.V) a += p.V[(long)bs[e] * p.ldv + n];     // (acc + bias) + (R + V): covered by the fixtures
-                            add[i][j][e] = a;
-                        }
+                        f32x4 a = f32x4{0.f, 0.f, 0.f, 0.f};
+                        if (p.R) a = *reinterpret_cast<const f32x4*>(&p.R[rows[i] * p.ldr + nl + j * 16]);
+                        if (p.V) a += *reinterpret_cast<const f32x4*>(&p.V[(long)bs * p.ldv + nl + j * 16]);   // (acc + bias) + (R + V)
+                        add[i][j] = a;
                     }
                 }
 #pragma unroll
-                for (int i = 0; i < MB; ++i)
+                for (int j = 0; j < NBW; ++j) {
+                    const f32x4 bv = *reinterpret_cast<const f32x4*>(&bias_lds[nl + j * 16]);
 #pragma unroll
-                    for (int j = 0; j < NBW; ++j) {
-                        const int n = n0 + wave * WN + j * 16 + l15;
-                        const float bv = bias_lds[n];
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            float v = (acc[i][j][e] + bv) + add[i][j][e];
-                            if (epi == EPI_GELU) v = gelu_fast(v);
-                            p.C[rows[i][e] * p.ldc + n] = v;
+                    for (int i = 0; i < MB; ++i) {
+                        f32x4 v = (acc[i][j] + bv) + add[i][j];
+                        if (epi == EPI_GELU) {
+                            const f32x2 lo = gelu_fast2(f32x2{v[0], v[1]}), hi = gelu_fast2(f32x2{v[2], v[3]});
+                            v = f32x4{lo.x, lo.y, hi.x, hi.y};
                         }
+                        *reinterpret_cast<f32x4*>(&p.C[rows[i] * p.ldc + nl + j * 16]) = v;
                         acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
                     }
+                }
             }
         }
         // the loaders have waited for slab g+2 before this barrier; step g+1 prefetches from it
@@ -402,7 +392,10 @@ int gemm2_num_cus() {
 
 bool gemm2_supported(int omode, int epi, const GemmParams& p) {
     return (omode == OUT_ROWS || omode == OUT_TOKROWS) && (epi == EPI_BIAS || epi == EPI_GELU) && p.K % 32 == 0 && p.N % 64 == 0 && p.N <= 8192 && p.lda % 4 == 0 &&
-           p.ldw % 4 == 0 && (long)(p.M + 128) * p.lda * 4 < (1L << 31) && (long)(p.N + 128) * p.ldw * 4 < (1L << 31);
+           p.ldw % 4 == 0 && (long)(p.M + 128) * p.lda * 4 < (1L << 31) && (long)(p.N + 128) * p.ldw * 4 < (1L << 31) &&
+           // float4 epilogue accesses: rows of C / R / V start on 16-byte boundaries
+           p.ldc % 4 == 0 && ((uintptr_t)p.C & 15) == 0 && (!p.R || (p.ldr % 4 == 0 && ((uintptr_t)p.R & 15) == 0)) &&
+           (!p.V || (p.ldv % 4 == 0 && ((uintptr_t)p.V & 15) == 0));
 }
 
 hipError_t launch_gemm2(int omode, int epi, const GemmParams& p, hipStream_t s) {
