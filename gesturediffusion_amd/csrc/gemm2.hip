@@ -23,7 +23,12 @@
 //   * the residual add of the out-proj / FFN-2 GEMMs moved into the LayerNorm kernel that follows (one extra
 //     operand stream in an HBM-bound kernel instead of 40 scattered loads per lane in the MFMA-bound one);
 //   * GELU uses a 12-instruction erf (Abramowitz-Stegun 7.1.26, |abs err| <= 1.5e-7) instead of the ~50-instruction
-//     libm erff: at fp32 MFMA rates the epilogue VALU is not free;
+//     libm erff: at fp32 MFMA rates the epilogue VALU is not free; it runs on two values per lane with packed-fp32
+//     instructions (v_pk_fma_f32 / v_pk_mul_f32), which left only the reciprocal and the exponential scalar
+//     (FFN-1 116.2 -> 112.5 us in situ);
+//   * the MFMA runs swapped (weight fragment = A operand): a lane then holds one output row and four consecutive
+//     columns per 16x16 block, so the epilogue adds the bias / hoisted terms and stores as float4 (one quarter of the
+//     store and address instructions; the general epilogue needs one sample index per lane instead of four);
 //   * tile height is a multiple of 16 rows, chosen per problem so that tiles / CUs lands just below an integer:
 //     BM = 80 turns M = 12 608 into 158 row tiles; with BN = 128 (N = 1024) or 64 (N = 512) that is 1 264 tiles
 //     = 4.94 per CU (98.8 % balance).  Tiles are walked lid, lid+G, ... in an XCD-aware order (the column tiles of
