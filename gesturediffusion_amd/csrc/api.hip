@@ -525,10 +525,11 @@ static int forward_core(gdx_model* h, const float* x, const float* temb, int tst
             HIPCHK(launch_attention2(h->qkv, h->ctx, Beff, S, h->H, d, s));
         else
             HIPCHK(launch_attention(h->qkv, h->ctx, Beff, S, h->H, d, s));
-        // x = LN1(x + out_proj(ctx)): the residual add rides in the LayerNorm kernel (see gemm2.hip)
-        p = GemmParams{h->ctx, d, ly.out.w, ly.out.kpad, ly.out.bias, nullptr, 0, nullptr, 0, h->tmp, d, N, d, d, T, B};
-        if (gemm(A_ROWS, B_WEIGHT, OUT_ROWS, EPI_BIAS, p, s)) return -1;
-        HIPCHK(launch_layernorm(h->tmp, h->xa, ly.g1, ly.b1, h->xb, nullptr, N, d, 0, s));
+        // x = LN1(x + out_proj(ctx)): the residual add rides in the GEMM epilogue (prefetched one tile ahead, gemm2.hip)
+        static const bool res_in_ln = getenv("GDX_RES_IN_LN") != nullptr;   // A/B switch: residual add in LayerNorm
+        p = GemmParams{h->ctx, d, ly.out.w, ly.out.kpad, ly.out.bias, res_in_ln ? nullptr : h->xa, d, nullptr, 0, h->tmp, d, N, d, d, T, B};
+        if (gemm(A_ROWS, B_WEIGHT, OUT_ROWS, res_in_ln ? EPI_BIAS : EPI_RES, p, s)) return -1;
+        HIPCHK(launch_layernorm(h->tmp, res_in_ln ? h->xa : nullptr, ly.g1, ly.b1, h->xb, nullptr, N, d, 0, s));
         p = GemmParams{h->xb, d, ly.ff1.w, ly.ff1.kpad, ly.ff1.bias, nullptr, 0, nullptr, 0, h->ffb, h->ff, N, h->ff, d, T, B};
         const bool stamp = h->prof && h->prof_used + 2 <= h->prof_ev.size();
         if (stamp) HIPCHK(hipEventRecord(h->prof_ev[h->prof_used], s));
@@ -537,12 +538,13 @@ static int forward_core(gdx_model* h, const float* x, const float* temb, int tst
             HIPCHK(hipEventRecord(h->prof_ev[h->prof_used + 1], s));
             h->prof_used += 2;
         }
-        p = GemmParams{h->ffb, h->ff, ly.ff2.w, ly.ff2.kpad, ly.ff2.bias, nullptr, 0, nullptr, 0, h->tmp, d, N, d, h->ff, T, B};
-        if (gemm(A_ROWS, B_WEIGHT, OUT_ROWS, EPI_BIAS, p, s)) return -1;
+        p = GemmParams{h->ffb, h->ff, ly.ff2.w, ly.ff2.kpad, ly.ff2.bias, res_in_ln ? nullptr : h->xb, d, nullptr, 0, h->tmp, d, N, d, h->ff, T, B};
+        if (gemm(A_ROWS, B_WEIGHT, OUT_ROWS, res_in_ln ? EPI_BIAS : EPI_RES, p, s)) return -1;
         const bool last = l + 1 == h->L;
+        const float* res2 = res_in_ln ? h->xb : nullptr;
         // the last layer's output is only needed without token 0 (model/mdm.py:219): write it compacted [Beff*T, d]
-        if (!last || h->keep_taps) HIPCHK(launch_layernorm(h->tmp, h->xb, ly.g2, ly.b2, h->xa, nullptr, N, d, 0, s));
-        if (last) HIPCHK(launch_layernorm(h->tmp, h->xb, ly.g2, ly.b2, h->xc, nullptr, N, d, S, s));
+        if (!last || h->keep_taps) HIPCHK(launch_layernorm(h->tmp, res2, ly.g2, ly.b2, h->xa, nullptr, N, d, 0, s));
+        if (last) HIPCHK(launch_layernorm(h->tmp, res2, ly.g2, ly.b2, h->xc, nullptr, N, d, S, s));
         if (h->keep_taps)
             HIPCHK(hipMemcpyAsync(h->taps[l + 1], h->xa, sizeof(float) * (size_t)N * d, hipMemcpyDeviceToDevice, s));
     }

@@ -20,8 +20,10 @@
 //     MFMA, issue their share of the DMA, and store their accumulators straight from registers; the bias vector
 //     is copied to LDS once per launch so the tile loop contains NO ordinary global load (one would make hipcc
 //     drain the DMA pipeline with vmcnt(0));
-//   * the residual add of the out-proj / FFN-2 GEMMs moved into the LayerNorm kernel that follows (one extra
-//     operand stream in an HBM-bound kernel instead of 40 scattered loads per lane in the MFMA-bound one);
+//   * the residual add of the out-proj / FFN-2 GEMMs: first moved into the LayerNorm kernel that follows (one extra
+//     operand stream in an HBM-bound kernel instead of 40 scattered 4-byte loads per lane in the MFMA-bound one); with
+//     the swapped accumulator layout it is 5-10 float4 loads per lane per tile, and the RESP variant of the kernel
+//     fetches them one tile ahead, so the add is back in the epilogue and LayerNorm reads one stream less;
 //   * GELU uses a 12-instruction erf (Abramowitz-Stegun 7.1.26, |abs err| <= 1.5e-7) instead of the ~50-instruction
 //     libm erff: at fp32 MFMA rates the epilogue VALU is not free; it runs on two values per lane with packed-fp32
 //     instructions (v_pk_fma_f32 / v_pk_mul_f32), which left only the reciprocal and the exponential scalar
@@ -94,7 +96,11 @@ __device__ __forceinline__ void g4_sched_interleave() {
     }
 }
 
-template <int MB, int NBW, int BK, int NST>
+// RESP: the residual variant (out-proj / FFN-2: C = A W^T + bias + R, R [M][ldr] row-aligned with C).  The R block of a
+// tile is loaded into registers when the PREVIOUS tile's epilogue ends, so its L2 / HBM latency is covered by the
+// tile's whole K loop (the MFMA waves issue no other global load, so their vmcnt is free for this); loading it in the
+// epilogue cost ~1 us per tile (A/B: +25 us per step even though LayerNorm lost its third stream).
+template <int MB, int NBW, int BK, int NST, bool RESP>
 __global__ __launch_bounds__(512, 1) void gemm4_kernel(const GemmParams p, const int epi, const int omode, const int ntn,
                                                        const int ntiles, unsigned long long* dbg) {
 #if defined(__HIP_DEVICE_COMPILE__)   // the host pass only needs the launch stub (the buffer-resource builtins are device-only)
@@ -231,6 +237,21 @@ __global__ __launch_bounds__(512, 1) void gemm4_kernel(const GemmParams p, const
     // start of this group's 4 * MB * NBW MFMAs; left to itself the compiler sinks them to the end of the MFMA block and
     // the next group then waits out the LDS latency (~120 cycles per group); A/B in one session: 0-4 % faster
     auto interleave = [&]() { g4_sched_interleave<0, MB + NBW, 4 * MB * NBW>(); };
+    f32x4 radd[RESP ? MB : 1][RESP ? NBW : 1];
+    auto load_res = [&](int tile) {
+        if constexpr (RESP) {
+            const int m0 = (tile / ntn) * BM, nl = (tile % ntn) * BN + wave * WN + 4 * lq;
+#pragma unroll
+            for (int i = 0; i < MB; ++i) {
+                int m = m0 + i * 16 + l15;
+                m = m < p.M ? m : p.M - 1;                      // rows past M are stored but never consumed
+                const float* rp = p.R + (long)m * p.ldr + nl;
+#pragma unroll
+                for (int j = 0; j < NBW; ++j) radd[i][j] = *reinterpret_cast<const f32x4*>(rp + j * 16);
+            }
+        }
+    };
+    load_res(lid);
     for (int g = 0; g < total; ++g) {
         const int nstage = stage == NST - 1 ? 0 : stage + 1;
         rd(fa1, fb1, stage, 1);
@@ -258,7 +279,19 @@ __global__ __launch_bounds__(512, 1) void gemm4_kernel(const GemmParams p, const
             const int m0 = (tile / ntn) * BM, n0 = (tile % ntn) * BN;
             const bool rowmap = omode == OUT_TOKROWS;
             const int nl = n0 + wave * WN + 4 * lq;                 // this lane's first column of block j = 0
-            if (!rowmap && !p.R && !p.V) {
+            if constexpr (RESP) {
+                float* cp = p.C + (long)(m0 + l15) * p.ldc + nl;
+#pragma unroll
+                for (int j = 0; j < NBW; ++j) {
+                    const f32x4 bv = *reinterpret_cast<const f32x4*>(&bias_lds[nl + j * 16]);
+#pragma unroll
+                    for (int i = 0; i < MB; ++i) {
+                        *reinterpret_cast<f32x4*>(cp + (long)(i * 16) * p.ldc + j * 16) = (acc[i][j] + bv) + radd[i][j];
+                        acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    }
+                }
+                if (g + 1 < total) load_res(lid + tile_i * G);  // the next tile's block, in flight during its K loop
+            } else if (!rowmap && !p.R && !p.V) {
                 // plain epilogue (the four encoder GEMMs)
                 float* cp = p.C + (long)(m0 + l15) * p.ldc + nl;
 #pragma unroll
@@ -341,14 +374,17 @@ constexpr size_t g4_lds_bytes(int N) {
     return (size_t)NST * (A_BYTES + W_BYTES) + (size_t)N * 4;
 }
 
-template <int MB, int NBW, int BK, int NST>
+template <int MB, int NBW, int BK, int NST, bool RESP = false>
 static hipError_t launch_cfg(const GemmParams& p, int epi, int omode, int num_cus, hipStream_t s) {
+    if constexpr (!RESP && MB * NBW <= 10) {                     // (the residual block costs 4 * MB * NBW registers)
+        if (p.R && !p.V && omode == OUT_ROWS && epi == EPI_BIAS) return launch_cfg<MB, NBW, BK, NST, true>(p, epi, omode, num_cus, s);
+    }
     constexpr int BM = MB * 16, BN = NBW * 64;
     static_assert(g4_lds_bytes<MB, NBW, BK, NST>(1024) <= 160 * 1024, "tile does not fit the 160 KiB LDS");
     const size_t lds = g4_lds_bytes<MB, NBW, BK, NST>(p.N);
     static size_t attr_lds = 0;
     if (lds > attr_lds) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm4_kernel<MB, NBW, BK, NST>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm4_kernel<MB, NBW, BK, NST, RESP>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         attr_lds = lds;
@@ -356,7 +392,7 @@ static hipError_t launch_cfg(const GemmParams& p, int epi, int omode, int num_cu
     const int ntm = (p.M + BM - 1) / BM, ntn = p.N / BN;
     const int ntiles = ntm * ntn;
     const int grid = ntiles < num_cus ? ntiles : num_cus;
-    hipLaunchKernelGGL((gemm4_kernel<MB, NBW, BK, NST>), dim3(grid), dim3(512), lds, s, p, epi, omode, ntn, ntiles,
+    hipLaunchKernelGGL((gemm4_kernel<MB, NBW, BK, NST, RESP>), dim3(grid), dim3(512), lds, s, p, epi, omode, ntn, ntiles,
                        g2_dbg_buf);
     return hipGetLastError();
 }
