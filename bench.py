@@ -202,10 +202,10 @@ def main():
         gemm_flops = 2.0 * N * d * ff
         traffic, traffic_src = None, None
         f16_mode = args.dtype == "fp16"
-        pmc = os.path.join(REPO, "profiles", "r01e_pmc_ffn1_traffic.json")
+        pmc = os.path.join(REPO, "profiles", "r01g_pmc_ffn1_traffic.json")
         if os.path.exists(pmc) and not args.cfg and not f16_mode and (B, T, d, args.arch) == (64, 196, 512, "mdm_old"):
             traffic = json.load(open(pmc))["hbm_bytes_per_launch"]     # PMC passes cannot run inside this process
-            traffic_src = "profiles/r01e_pmc_ffn1_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this bench)"
+            traffic_src = "profiles/r01g_pmc_ffn1_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this bench)"
         achieved = gemm_flops / (gemm_us * 1e-6) / 1e12
         f16 = args.dtype == "fp16"
         peak = F16_MFMA_PEAK_TFLOPS if f16 else F32_MFMA_PEAK_TFLOPS
