@@ -343,6 +343,30 @@ def test_full_size_properties_config2():
     assert torch.equal(r64[8:12], r4)
 
 
+@pytest.mark.parametrize("arch,B,T", [("mdm_old", 256, 196), ("mdm", 64, 200), ("mdm", 256, 200)])
+def test_full_size_properties_configs_3_4(arch, B, T):
+    """BASELINE configs 3 / 4 per-GPU sizes (B = 256, with classifier-free guidance an effective batch of 512 rows:
+    M = 100 864 GEMM rows, 2 048 attention workgroups) and the V2 topology at its full size: rows of the big batch equal
+    the same samples run as a batch of 2, bit for bit, for the plain forward and for the guided blend."""
+    from gesturediffusion_amd.model.cfg_sampler import ClassifierFreeSampleModel
+    from gesturediffusion_amd.utils.init import init_state_dict, synthetic_inputs
+    cfg = _real_cfg(arch, 263, 512)
+    m = build_model(arch, cfg, init_state_dict(cfg, seed=0))
+    d = dev()
+    x, seedp, mfcc = synthetic_inputs(cfg, B, T, seed=10)
+    t = torch.full((B,), 77, device=d)
+    lo = B - 3
+    y = {"seed": seedp.to(d), "mfcc": mfcc.to(d)}
+    y2 = {"seed": seedp[lo:lo + 2].to(d), "mfcc": mfcc[lo:lo + 2].to(d)}
+    full = m(x.to(d), t, y)
+    assert torch.isfinite(full).all()
+    assert torch.equal(full[lo:lo + 2], m(x[lo:lo + 2].to(d), t[:2], y2))
+    g = ClassifierFreeSampleModel(m)
+    full_g = g(x.to(d), t, dict(y, scale=torch.full((B,), 2.5, device=d)))
+    assert torch.isfinite(full_g).all()
+    assert torch.equal(full_g[lo:lo + 2], g(x[lo:lo + 2].to(d), t[:2], dict(y2, scale=torch.full((2,), 2.5, device=d))))
+
+
 def test_error_behaviour_matches_reference(golden_dir):
     import os
     from gesturediffusion_amd.utils.init import init_state_dict, synthetic_inputs
