@@ -250,7 +250,7 @@ int gdx_profile_end(gdx_handle_t h, float* avg_us, int32_t* launches);
  * (0 bias, 1 bias+GELU, 2 bias+residual) on scratch buffers filled with N(0,1). */
 int gdx_bench_gemm(int32_t M, int32_t N, int32_t K, int32_t epi, int32_t iters, float* avg_us, void* stream);
 /* Time `iters` launches of the self-attention core on scratch qkv [B*S][3d] (version 1 = attention.hip,
- * 2 = attention2.hip where supported, 3 = the fp16 kernel attentionh.hip). */
+ * 2 = attention2.hip where supported, 3 = the fp16 kernel attentionh.hip, 4 = attention3.hip where supported). */
 int gdx_bench_attention(int32_t B, int32_t S, int32_t H, int32_t d, int32_t version, int32_t iters,
                         float* avg_us, void* stream);
 /* ---- reduced-precision building blocks (tests / measurement) ---------------------------- */
