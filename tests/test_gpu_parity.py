@@ -496,6 +496,32 @@ def test_fp32_attention_vs_torch(B, S, H, dm, version):
     assert rel_err(ctx.cpu().double(), ref.cpu()) < 2e-6
 
 
+@pytest.mark.parametrize("hd", [64, 128])
+def test_fp32_attention3_every_block_count(hd):
+    """attention3.hip at every query-block count 1..16 (sequence lengths 16 k - 15 and 16 k - 3): with / without the
+    shared last block, 1..4 K/V tiles, waves with 0, 1 or 2 own blocks, masked tail of 1 and 13 keys."""
+    import ctypes as C
+    from gesturediffusion_amd import _lib
+    lib = _lib.load()
+    d = dev()
+    H = 2
+    dm = H * hd
+    s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    for k in range(1, 17):
+        for S in (16 * k - 15, 16 * k - 3):
+            B = 3
+            g = torch.Generator(device=d).manual_seed(1000 * hd + S)
+            qkv = torch.randn(B * S, 3 * dm, device=d, generator=g)
+            qkv[:, :dm] *= 2.0
+            ctx = torch.full((B * S, dm), float("nan"), device=d)
+            _lib.check(lib.gdx_attention_f32(C.c_void_p(qkv.data_ptr()), C.c_void_p(ctx.data_ptr()), B, S, H, dm, 3, s), lib)
+            r = qkv.double().view(B, S, 3, H, hd)
+            q, kk, v = (r[:, :, i].permute(0, 2, 1, 3) for i in range(3))
+            p = torch.softmax(q @ kk.transpose(-1, -2) / hd ** 0.5, dim=-1)
+            ref = (p @ v).permute(0, 2, 1, 3).reshape(B * S, dm)
+            assert rel_err(ctx.cpu().double(), ref.cpu()) < 2e-6, (hd, S)
+
+
 @pytest.mark.parametrize("name,arch,J,dm", [("c1_v2", "mdm", 150, 512), ("c2_v1", "mdm_old", 263, 512),
                                             ("c5_v2", "mdm", 498, 1024)])
 def test_fp16_mode_real_shapes_vs_reference_golden(name, arch, J, dm):
