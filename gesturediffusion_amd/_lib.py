@@ -14,12 +14,14 @@ LIB_PATH = os.environ.get("GDX_LIBGDX") or os.path.join(_HERE, "csrc", "libgdx.s
 GDX_ARCH_MDM_OLD, GDX_ARCH_MDM = 1, 2
 GDX_COND, GDX_UNCOND, GDX_CFG = 0, 1, 2
 GDX_SAMPLER_P, GDX_SAMPLER_DDIM = 0, 1
+GDX_ROW_PAD = 256      # include/gdx.h
 
 EXPORTS = [
     "gdx_create", "gdx_destroy", "gdx_last_error", "gdx_set_weight", "gdx_weights_ready", "gdx_prepare",
     "gdx_set_condition", "gdx_forward", "gdx_set_keep_taps", "gdx_get_tap", "gdx_sampler_update", "gdx_q_sample",
     "gdx_randn", "gdx_sample_loop", "gdx_bench_ffn_gemm", "gdx_bench_gemm", "gdx_forward_flops", "gdx_profile_begin", "gdx_profile_end", "gdx_bench_attention",
     "gdx_linear_f16", "gdx_bench_gemm_f16", "gdx_attention_f16", "gdx_attention_f32", "gdx_plms_update", "gdx_postprocess", "gdx_q_sample_t", "gdx_masked_l2", "gdx_set_graph_replay", "gdx_mfcc",
+    "gdx_set_guards", "gdx_check_guards",
 ]
 
 
@@ -59,6 +61,7 @@ class LoopArgs(C.Structure):
         ("inpaint_mask", C.c_void_p), ("inpaint_motion", C.c_void_p), ("noise_tape", C.c_void_p),
         ("const_noise", C.c_int32), ("philox_seed", C.c_uint64), ("sample_offset", C.c_uint64),
         ("dump", C.c_void_p), ("dump_steps", C.c_void_p), ("n_dump", C.c_int32),
+        ("run_steps", C.c_int32), ("k_base", C.c_int32),
     ]
 
 
@@ -110,6 +113,8 @@ def load():
         "gdx_attention_f16": [vp, vp, i32, i32, i32, i32, vp],
         "gdx_attention_f32": [vp, vp, i32, i32, i32, i32, i32, vp],
         "gdx_bench_gemm_f16": [i32, i32, i32, i32, i32, C.POINTER(C.c_float), vp],
+        "gdx_set_guards": [vp, i32],
+        "gdx_check_guards": [vp, C.POINTER(i64), C.POINTER(i32), vp],
         "gdx_profile_begin": [vp, i32],
         "gdx_profile_end": [vp, C.POINTER(C.c_float), C.POINTER(i32)],
     }

@@ -93,6 +93,8 @@ struct gdx_model {
     float* c2t_table = nullptr;       // V2: W_coa * temb_table rows (valid while c2t_valid)
     float* c2_seed = nullptr;         // V2: W_coa * seed_cat rows [2B, d]
     bool c2t_valid = false;
+    bool tables_valid = false;        // temb_table (and c2t_table) hold the rows of tmap_host under the current weights
+    std::vector<int64_t> tmap_host;
     // graph replay of launch-bound loops (gdx_sample_loop)
     bool graph_replay = false;        // gdx_set_graph_replay
     int* gstate = nullptr;            // device {schedule index, executed-step number}
@@ -106,7 +108,12 @@ struct gdx_model {
     size_t prof_used = 0;
     bool keep_taps = false;
     std::vector<float*> taps;         // [L+1] x [2B*S*d] when keep_taps
+    bool guards = false;              // gdx_set_guards: every workspace allocation carries a canary zone behind it
+    std::vector<std::pair<unsigned char*, size_t>> guard_zones;
 };
+
+static constexpr size_t GUARD_BYTES = 64 * 1024;
+static constexpr int GUARD_BYTE = 0xA5;
 
 static int dev_alloc(std::vector<void*>& pool, void** p, size_t bytes) {
     hipError_t e = hipMalloc(p, bytes ? bytes : 16);
@@ -335,6 +342,7 @@ extern "C" int gdx_set_weight(gdx_handle_t h, const char* name_c, const float* p
     h->have.insert(name);
     h->cond_set = false;
     h->c2t_valid = false;
+    h->tables_valid = false;
     return 0;
 }
 
@@ -357,18 +365,29 @@ extern "C" int gdx_prepare(gdx_handle_t h, int32_t batch, int32_t frames) {
         return fail("gdx_prepare: frames exceed rotary table");
     if (h->B == batch && h->T == frames) return 0;
     free_pool(h->ws_allocs);
+    h->guard_zones.clear();
     h->taps.clear();
     h->temb_table = nullptr; h->temb_table_rows = 0; h->tmap_dev = nullptr; h->c2t_table = nullptr; h->c2t_valid = false;
-    h->B = batch; h->T = frames; h->S = frames + 1; h->cond_set = false;
-    // +128 rows: the persistent GEMM reads / stores whole tiles past the last logical row (gemm2.hip)
-    const size_t B2 = 2 * (size_t)batch, N = B2 * h->S + 128, d = h->d;
+    h->tables_valid = false;
+    // the shape is recorded only once every allocation has succeeded: after a failed hipMalloc a retry with the same
+    // shape must allocate again instead of returning early on partial buffers
+    h->B = 0; h->T = 0; h->S = frames + 1; h->cond_set = false;
+    // + GDX_ROW_PAD rows: the persistent GEMM reads / stores whole tiles past the last logical row (gemm2.hip; its
+    // tallest tile is checked against the pad at compile time)
+    const size_t B2 = 2 * (size_t)batch, N = B2 * h->S + GDX_ROW_PAD, d = h->d;
     h->rows_alloc = (long)N;
     // zero-filled: the padding rows are read by whole-tile GEMMs / K-V tiles and must stay finite
-    auto A = [&](float** p, size_t n) {
-        if (dev_alloc(h->ws_allocs, (void**)p, n * sizeof(float))) return -1;
-        if (hipMemset(*p, 0, n * sizeof(float)) != hipSuccess) return fail("gdx_prepare: hipMemset failed");
+    auto raw = [&](void** p, size_t bytes) {
+        if (dev_alloc(h->ws_allocs, p, bytes + (h->guards ? GUARD_BYTES : 0))) return -1;
+        if (hipMemset(*p, 0, bytes) != hipSuccess) return fail("gdx_prepare: hipMemset failed");
+        if (h->guards) {
+            unsigned char* g = (unsigned char*)*p + bytes;
+            if (hipMemset(g, GUARD_BYTE, GUARD_BYTES) != hipSuccess) return fail("gdx_prepare: hipMemset failed");
+            h->guard_zones.emplace_back(g, bytes);
+        }
         return 0;
     };
+    auto A = [&](float** p, size_t n) { return raw((void**)p, n * sizeof(float)); };
     if (A(&h->xa, N * d) || A(&h->addend, N * d) || A(&h->seed_cat, B2 * d) || A(&h->temb_in, B2 * d) ||
         A(&h->temb_h, B2 * d) || A(&h->temb, B2 * d) || A(&h->coa, B2 * d) || A(&h->c2, (B2 + 1) * d) ||
         A(&h->c2_seed, B2 * d) ||
@@ -378,17 +397,13 @@ extern "C" int gdx_prepare(gdx_handle_t h, int32_t batch, int32_t frames) {
     if (!h->f16 && (A(&h->xb, N * d) || A(&h->qkv, N * 3 * d) || A(&h->ctx, N * d) || A(&h->tmp, N * d) || A(&h->ffb, N * h->ff)))
         return -1;
     h->ldo = round_up(h->J, 64);
-    const size_t NT = B2 * frames + 128;
+    const size_t NT = B2 * frames + GDX_ROW_PAD;
     if (A(&h->x0t, NT * h->ldo)) return -1;
     if (!h->f16 && (A(&h->xt, NT * round_up(h->J, 32)) || A(&h->xc, NT * d))) return -1;
     if (h->cfg.arch == GDX_ARCH_MDM && A(&h->xseq, NT * d)) return -1;
     if (h->cfg.arch == GDX_ARCH_MDM && !h->f16 && A(&h->emb_pose, NT * d)) return -1;
     if (h->f16) {
-        auto H16 = [&](_Float16** p, size_t n) {
-            if (dev_alloc(h->ws_allocs, (void**)p, n * 2)) return -1;
-            if (hipMemset(*p, 0, n * 2) != hipSuccess) return fail("gdx_prepare: hipMemset failed");
-            return 0;
-        };
+        auto H16 = [&](_Float16** p, size_t n) { return raw((void**)p, n * 2); };
         if (H16(&h->xt16, NT * round_up(h->J, 64)) || H16(&h->xa16, N * d) || H16(&h->xb16, N * d) ||
             H16(&h->qkv16, N * 3 * d) || H16(&h->ctx16, N * d) || H16(&h->tmp16, N * d) || H16(&h->ffb16, N * h->ff) || H16(&h->xc16, NT * d))
             return -1;
@@ -399,6 +414,37 @@ extern "C" int gdx_prepare(gdx_handle_t h, int32_t batch, int32_t frames) {
         for (auto& t : h->taps)
             if (A(&t, N * d)) return -1;
     }
+    h->B = batch; h->T = frames;
+    return 0;
+}
+
+extern "C" int gdx_set_guards(gdx_handle_t h, int32_t on) {
+    if (!h) return fail("gdx_set_guards: null handle");
+    if (h->guards != (on != 0)) {
+        h->guards = on != 0;
+        const int B = h->B, T = h->T;
+        if (B) {
+            h->B = 0;
+            return gdx_prepare(h, B, T);
+        }
+    }
+    return 0;
+}
+
+extern "C" int gdx_check_guards(gdx_handle_t h, int64_t* bad_bytes, int32_t* first_bad_zone, void* stream) {
+    if (!h || !bad_bytes) return fail("gdx_check_guards: null argument");
+    if (!h->guards) return fail("gdx_check_guards: guards are off (gdx_set_guards)");
+    HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+    std::vector<unsigned char> host(GUARD_BYTES);
+    int64_t bad = 0;
+    int first = -1;
+    for (size_t z = 0; z < h->guard_zones.size(); ++z) {
+        HIPCHK(hipMemcpy(host.data(), h->guard_zones[z].first, GUARD_BYTES, hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < GUARD_BYTES; ++i)
+            if (host[i] != GUARD_BYTE) { ++bad; if (first < 0) first = (int)z; }
+    }
+    *bad_bytes = bad;
+    if (first_bad_zone) *first_bad_zone = first;
     return 0;
 }
 
@@ -654,7 +700,7 @@ static int time_embed(gdx_model* h, const int64_t* idx, int M, float* gathered, 
     HIPCHK(launch_gather_rows(h->pe, idx, gathered, M, d, h->pe_rows, s));
     HIPCHK(launch_small_linear(gathered, d, h->time0.w, h->time0.kpad, h->time0.bias, hidden, d, M, d, d, 1, s));
     if (table && M >= 64) {   // whole-loop tables only (per-sample embeddings keep one batch-size-independent kernel):
-                              // the persistent GEMM; the caller pads `hidden` / `out` by >= 128 rows
+                              // the persistent GEMM; the caller pads `hidden` / `out` by >= GDX_ROW_PAD rows
         GemmParams p{hidden, d, h->time2.w, h->time2.kpad, h->time2.bias, nullptr, 0, nullptr, 0, out, d, M, d, d, 1, 1};
         return gemm(A_ROWS, B_WEIGHT, OUT_ROWS, EPI_BIAS, p, s);
     }
@@ -682,7 +728,8 @@ extern "C" int gdx_sample_loop(gdx_handle_t h, const gdx_loop_args_t* a, void* s
     if (!a || !a->coef || !a->timestep_map || !a->x) return fail("gdx_sample_loop: null argument");
     if (a->mode < GDX_COND || a->mode > GDX_CFG) return fail("gdx_sample_loop: bad mode");
     if (a->mode == GDX_CFG && !a->scale) return fail("gdx_sample_loop: GDX_CFG needs scale");
-    if (a->num_steps <= 0 || a->first_index >= a->num_steps) return fail("gdx_sample_loop: bad step range");
+    if (a->num_steps <= 0 || a->first_index >= a->num_steps || a->first_index < 0 || a->run_steps < 0 || a->k_base < 0)
+        return fail("gdx_sample_loop: bad step range");
     if (a->kind == GDX_SAMPLER_DDIM && (a->const_noise || a->n_dump))
         return fail("gdx_sample_loop: ddim_sample_loop supports neither const_noise nor dump_steps");  // :903-906
     hipStream_t s = (hipStream_t)stream;
@@ -691,17 +738,25 @@ extern "C" int gdx_sample_loop(gdx_handle_t h, const gdx_loop_args_t* a, void* s
     // gaussian_diffusion.py:712), through the respacing map (respace.py:124-129)
     if (h->temb_table_rows < a->num_steps) {
         float* t3 = nullptr;
-        // + 256 / + 128 rows: the table linears run on the persistent GEMM, which reads / stores whole tiles
-        if (dev_alloc(h->ws_allocs, (void**)&t3, sizeof(float) * (3 * (size_t)a->num_steps + 256) * d)) return -1;
-        HIPCHK(hipMemsetAsync(t3, 0, sizeof(float) * (3 * (size_t)a->num_steps + 256) * d, s));
-        if (h->cfg.arch == GDX_ARCH_MDM && dev_alloc(h->ws_allocs, (void**)&h->c2t_table, sizeof(float) * ((size_t)a->num_steps + 128) * d))
+        // + GDX_ROW_PAD rows behind the last of the three tables: the table linears run on the persistent GEMM, which
+        // reads / stores whole tiles
+        if (dev_alloc(h->ws_allocs, (void**)&t3, sizeof(float) * (3 * (size_t)a->num_steps + GDX_ROW_PAD) * d)) return -1;
+        HIPCHK(hipMemsetAsync(t3, 0, sizeof(float) * (3 * (size_t)a->num_steps + GDX_ROW_PAD) * d, s));
+        if (h->cfg.arch == GDX_ARCH_MDM && dev_alloc(h->ws_allocs, (void**)&h->c2t_table, sizeof(float) * ((size_t)a->num_steps + GDX_ROW_PAD) * d))
             return -1;
         if (dev_alloc(h->ws_allocs, (void**)&h->tmap_dev, sizeof(int64_t) * a->num_steps)) return -1;
         h->temb_table = t3;
         h->temb_table_rows = a->num_steps;
+        h->tables_valid = false; h->c2t_valid = false;
     }
-    HIPCHK(hipMemcpyAsync(h->tmap_dev, a->timestep_map, sizeof(int64_t) * a->num_steps, hipMemcpyHostToDevice, s));
     float* table = h->temb_table;
+    // the tables depend on the weights and the timestep map only: a loop run in blocks (run_steps) builds them once
+    const bool tables_live = h->tables_valid && (int)h->tmap_host.size() == a->num_steps &&
+                             !memcmp(h->tmap_host.data(), a->timestep_map, sizeof(int64_t) * a->num_steps) &&
+                             (h->cfg.arch != GDX_ARCH_MDM || h->c2t_valid);
+    if (!tables_live) {
+    h->tmap_host.assign(a->timestep_map, a->timestep_map + a->num_steps);
+    HIPCHK(hipMemcpyAsync(h->tmap_dev, h->tmap_host.data(), sizeof(int64_t) * a->num_steps, hipMemcpyHostToDevice, s));
     float* scratch0 = table + (size_t)h->temb_table_rows * d;
     float* scratch1 = scratch0 + (size_t)h->temb_table_rows * d;
     if (time_embed(h, h->tmap_dev, a->num_steps, scratch0, scratch1, table, true, s)) return -1;
@@ -715,9 +770,12 @@ extern "C" int gdx_sample_loop(gdx_handle_t h, const gdx_loop_args_t* a, void* s
         }
         h->c2t_valid = true;
     }
+    h->tables_valid = true;
+    }
 
     const int64_t per = (int64_t)h->J * h->T;
     int dump_i = 0;
+    while (dump_i < a->n_dump && a->dump_steps[dump_i] < a->k_base) ++dump_i;     // entries of earlier blocks
     auto fill_update = [&](gdx_update_args_t& u, int idx, int k) {
         memset(&u, 0, sizeof(u));
         u.kind = a->kind; u.batch = B; u.njoints = h->J; u.frames = h->T;
@@ -726,7 +784,7 @@ extern "C" int gdx_sample_loop(gdx_handle_t h, const gdx_loop_args_t* a, void* s
         u.x0_uncond = a->mode == GDX_CFG ? h->x0 + (size_t)B * per : nullptr;
         u.scale = a->scale;
         u.inpaint_mask = a->inpaint_mask; u.inpaint_motion = a->inpaint_motion;
-        u.noise = a->noise_tape ? a->noise_tape + (size_t)k * (a->const_noise ? 1 : B) * per : nullptr;
+        u.noise = a->noise_tape ? a->noise_tape + (size_t)(k - a->k_base) * (a->const_noise ? 1 : B) * per : nullptr;
         u.const_noise = a->const_noise;
         u.philox_seed = a->philox_seed; u.sample_offset = a->sample_offset; u.rng_step = (uint32_t)(k + 1);
         u.out = a->x; u.pred_xstart = nullptr;
@@ -736,9 +794,10 @@ extern "C" int gdx_sample_loop(gdx_handle_t h, const gdx_loop_args_t* a, void* s
         gdx_update_args_t u;
         fill_update(u, idx, k);
         if (gdx_sampler_update(&u, stream)) return -1;
-        if (a->dump && dump_i < a->n_dump && a->dump_steps[dump_i] == k) {
-            HIPCHK(hipMemcpyAsync(a->dump + (size_t)dump_i * B * per, a->x, sizeof(float) * B * per,
-                                  hipMemcpyDeviceToDevice, s));
+        while (a->dump && dump_i < a->n_dump && a->dump_steps[dump_i] <= k) {      // duplicates / stale entries never stall
+            if (a->dump_steps[dump_i] == k)
+                HIPCHK(hipMemcpyAsync(a->dump + (size_t)dump_i * B * per, a->x, sizeof(float) * B * per,
+                                      hipMemcpyDeviceToDevice, s));
             ++dump_i;
         }
         return 0;
@@ -750,8 +809,9 @@ extern "C" int gdx_sample_loop(gdx_handle_t h, const gdx_loop_args_t* a, void* s
     // ROCm 7.2 (tools/small_loop.py, 1000 steps, B=4 T=60 d=512 fp16): eager 0.307 ms/step, graph replay 0.337 -- the
     // ~65 small kernels of a step are bound by their GPU-side dispatch + ramp, not by host launch time, and a graph
     // node costs slightly more than a stream launch; so it is OFF by default and kept as a switch.
-    const bool want_graph = h->graph_replay && !h->prof && !h->keep_taps && !a->n_dump && a->first_index >= 8;
-    int idx = a->first_index, k = 0;
+    const int last_idx = a->run_steps > 0 && a->run_steps <= a->first_index ? a->first_index - a->run_steps + 1 : 0;
+    const bool want_graph = h->graph_replay && !h->prof && !h->keep_taps && !a->n_dump && a->first_index - last_idx >= 8;
+    int idx = a->first_index, k = a->k_base;
     if (want_graph) {
         if (eager_step(idx, k)) return -1;                        // step 0 eagerly: it also sets every kernel attribute
         --idx; ++k;
@@ -777,7 +837,8 @@ extern "C" int gdx_sample_loop(gdx_handle_t h, const gdx_loop_args_t* a, void* s
             if (!rc) {
                 gdx_update_args_t u;
                 fill_update(u, 0, 0);
-                u.noise = a->noise_tape;                          // base; the kernel adds state[1] * stride
+                u.noise = a->noise_tape ? a->noise_tape - (size_t)a->k_base * (a->const_noise ? 1 : B) * per : nullptr;
+                                                                  // base; the kernel adds state[1] * stride
                 rc = gdx_sampler_update_state_(&u, h->gstate, (long)(a->const_noise ? 1 : B) * per, (void*)h->gstream);
             }
             if (!rc && launch_advance_state(h->gstate, h->gstream) != hipSuccess) rc = -1;
@@ -800,14 +861,14 @@ extern "C" int gdx_sample_loop(gdx_handle_t h, const gdx_loop_args_t* a, void* s
             (void)hipGetLastError();
         }
         if (ok) {
-            for (; idx >= 0; --idx, ++k) HIPCHK(hipGraphLaunch(h->gexec, h->gstream));
+            for (; idx >= last_idx; --idx, ++k) HIPCHK(hipGraphLaunch(h->gexec, h->gstream));
             HIPCHK(hipEventRecord(h->gev_out, h->gstream));
             HIPCHK(hipStreamWaitEvent(s, h->gev_out, 0));
             return 0;
         }
         g_err.clear();                                            // capture unavailable: finish the loop eagerly
     }
-    for (; idx >= 0; --idx, ++k)
+    for (; idx >= last_idx; --idx, ++k)
         if (eager_step(idx, k)) return -1;
     return 0;
 }
@@ -817,7 +878,7 @@ extern "C" int gdx_sample_loop(gdx_handle_t h, const gdx_loop_args_t* a, void* s
 //   dft  [2*nbp][Lp]   rows k < nbins: cos(2 pi k i / nfft), rows nbp + k: -sin(...), zero elsewhere; Lp = frame_len up to 32,
 //                      nbp = nbins up to 64
 //   mel  [64][nbp]     rows j < nfilt: triangular filter j over the nbins power bins, zero elsewhere
-//   work               (numframes + 128) * (Lp + 2*nbp + nbp + 64) + numframes floats
+//   work               (numframes + GDX_ROW_PAD) * (Lp + 2*nbp + nbp + 64) + numframes floats
 extern "C" int gdx_mfcc(const float* signal, int64_t n, int32_t frame_len, int32_t frame_step, int32_t numframes,
                         int32_t nfft, int32_t nfilt, int32_t numcep, float preemph, const float* dft, const float* mel,
                         const float* dct, const float* lifter, const float* mean, const float* stdv, float* work,
@@ -829,7 +890,7 @@ extern "C" int gdx_mfcc(const float* signal, int64_t n, int32_t frame_len, int32
     hipStream_t s = (hipStream_t)stream;
     hipError_t e = gemm_init();
     if (e != hipSuccess) return fail(std::string("gemm_init: ") + hipGetErrorString(e));
-    const int nbins = nfft / 2 + 1, Lp = round_up(frame_len, 32), nbp = round_up(nbins, 64), rows = numframes + 128;
+    const int nbins = nfft / 2 + 1, Lp = round_up(frame_len, 32), nbp = round_up(nbins, 64), rows = numframes + GDX_ROW_PAD;
     float* frames = work;
     float* spec = frames + (size_t)rows * Lp;
     float* pw = spec + (size_t)rows * 2 * nbp;
@@ -930,9 +991,9 @@ extern "C" int gdx_bench_gemm(int32_t M, int32_t N, int32_t K, int32_t epi, int3
     const int npad = round_up(N, 128);
     float *A = nullptr, *W = nullptr, *bias = nullptr, *R = nullptr, *C = nullptr;
     std::vector<void*> pool;
-    if (dev_alloc(pool, (void**)&A, sizeof(float) * (size_t)(M + 128) * K) || dev_alloc(pool, (void**)&W, sizeof(float) * (size_t)npad * K) ||
+    if (dev_alloc(pool, (void**)&A, sizeof(float) * (size_t)(M + GDX_ROW_PAD) * K) || dev_alloc(pool, (void**)&W, sizeof(float) * (size_t)npad * K) ||
         dev_alloc(pool, (void**)&bias, sizeof(float) * npad) || dev_alloc(pool, (void**)&R, sizeof(float) * (size_t)M * N) ||
-        dev_alloc(pool, (void**)&C, sizeof(float) * (size_t)(M + 128) * N)) {
+        dev_alloc(pool, (void**)&C, sizeof(float) * (size_t)(M + GDX_ROW_PAD) * N)) {
         free_pool(pool);
         return -1;
     }
@@ -1029,7 +1090,7 @@ extern "C" int gdx_attention_f16(const float* qkv, float* ctx, int32_t B, int32_
 }
 
 // fp32 SDPA core on a caller's [B*S][3d] buffer (test entry point).  The kernels read whole K/V tiles past the last
-// sample, so the call works on a scratch copy with 128 zero rows behind it, like the workspace of gdx_prepare.
+// sample, so the call works on a scratch copy with GDX_ROW_PAD zero rows behind it, like the workspace of gdx_prepare.
 extern "C" int gdx_attention_f32(const float* qkv, float* ctx, int32_t B, int32_t S, int32_t H, int32_t d, int32_t version,
                                  void* stream) {
     if (!qkv || !ctx || B <= 0 || S <= 0 || H <= 0 || d <= 0 || d % H) return fail("gdx_attention_f32: bad argument");
@@ -1038,7 +1099,7 @@ extern "C" int gdx_attention_f32(const float* qkv, float* ctx, int32_t B, int32_
     if ((version == 2 && !attention2_supported(S, H, d)) || (version == 3 && !attention3_supported(S, H, d)))
         return fail("gdx_attention_f32: shape not supported by the requested kernel");
     hipStream_t s = (hipStream_t)stream;
-    const size_t rows = (size_t)B * S, prow = rows + 128;
+    const size_t rows = (size_t)B * S, prow = rows + GDX_ROW_PAD;
     float *q = nullptr, *c = nullptr;
     std::vector<void*> pool;
     int rc = 0;
@@ -1126,7 +1187,7 @@ extern "C" int gdx_bench_attention(int32_t B, int32_t S, int32_t H, int32_t d, i
     hipStream_t s = (hipStream_t)stream;
     float *qkv = nullptr, *ctx = nullptr;
     std::vector<void*> pool;
-    const size_t rows = (size_t)B * S + 128;
+    const size_t rows = (size_t)B * S + GDX_ROW_PAD;
     if (dev_alloc(pool, (void**)&qkv, sizeof(float) * rows * 3 * d) || dev_alloc(pool, (void**)&ctx, sizeof(float) * rows * d)) {
         free_pool(pool);
         return -1;

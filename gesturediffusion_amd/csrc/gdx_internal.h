@@ -3,7 +3,13 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "../../include/gdx.h"
+
 namespace gdx {
+
+// Rows every token-major workspace buffer carries beyond its last logical row (include/gdx.h): the persistent GEMM
+// (gemm2.hip) reads and stores WHOLE tiles, the attention kernels read whole K/V tiles.  Must be >= the tallest tile.
+constexpr int ROW_PAD = GDX_ROW_PAD;
 
 // ---- GEMM (gemm.hip) ---------------------------------------------------------------------
 // C = A * W^T (+ epilogue).  W is a packed weight [Npad][ldw], K-contiguous, zero padded to

@@ -35,8 +35,10 @@
 //     BM = 80 turns M = 12 608 into 158 row tiles; with BN = 128 (N = 1024) or 64 (N = 512) that is 1 264 tiles
 //     = 4.94 per CU (98.8 % balance).  Tiles are walked lid, lid+G, ... in an XCD-aware order (the column tiles of
 //     one row panel run on one XCD and share its L2).
-// Contract with the caller (api.hip): A and C have at least 128 readable / writable rows beyond M (workspace
-// padding): the last row tile reads and stores whole tiles, its surplus rows are garbage that nothing consumes.
+// Contract with the caller (api.hip): A and C have at least ROW_PAD (gdx_internal.h) readable / writable rows beyond M
+// (workspace padding): the last row tile reads whole tiles and, in the plain / residual epilogues, stores whole tiles
+// (its surplus rows are garbage that nothing consumes; ROW_PAD >= the tallest tile is a static_assert in launch_cfg).
+// The general epilogue (boundary linears: token-row map, R, V) moves rows, so it guards every access with m < M.
 // Summation order per output element is k-slab by k-slab and does not depend on the tile shape, so results are
 // independent of batch size / tile choice (tests/test_gpu_parity.py::test_full_size_properties_config2).
 #include "gdx_internal.h"
@@ -328,12 +330,16 @@ __global__ __launch_bounds__(512, 1) void gemm4_kernel(const GemmParams p, const
                         bs = p.T >= 16 ? bb0 + (r >= p.T ? 1 : 0) : bb0 + r / p.T;
                     }
                     const int m = m0 + i * 16 + l15;
-                    rows[i] = rowmap ? (long)m + bs + 1 : (long)m;
+                    // rows past M: the row map shifts them by the sample index, which can carry them beyond the padding
+                    // (and bs beyond V) -- they are neither loaded nor stored
+                    rows[i] = m >= p.M ? -1L : rowmap ? (long)m + bs + 1 : (long)m;
 #pragma unroll
                     for (int j = 0; j < NBW; ++j) {
                         f32x4 a = f32x4{0.f, 0.f, 0.f, 0.f};
-                        if (p.R) a = *reinterpret_cast<const f32x4*>(&p.R[rows[i] * p.ldr + nl + j * 16]);
-                        if (p.V) a += *reinterpret_cast<const f32x4*>(&p.V[(long)bs * p.ldv + nl + j * 16]);   // (acc + bias) + (R + V)
+                        if (rows[i] >= 0) {
+                            if (p.R) a = *reinterpret_cast<const f32x4*>(&p.R[rows[i] * p.ldr + nl + j * 16]);
+                            if (p.V) a += *reinterpret_cast<const f32x4*>(&p.V[(long)bs * p.ldv + nl + j * 16]);   // (acc + bias) + (R + V)
+                        }
                         add[i][j] = a;
                     }
                 }
@@ -347,7 +353,7 @@ __global__ __launch_bounds__(512, 1) void gemm4_kernel(const GemmParams p, const
                             const f32x2 lo = gelu_fast2(f32x2{v[0], v[1]}), hi = gelu_fast2(f32x2{v[2], v[3]});
                             v = f32x4{lo.x, lo.y, hi.x, hi.y};
                         }
-                        *reinterpret_cast<f32x4*>(&p.C[rows[i] * p.ldc + nl + j * 16]) = v;
+                        if (rows[i] >= 0) *reinterpret_cast<f32x4*>(&p.C[rows[i] * p.ldc + nl + j * 16]) = v;
                         acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
                     }
                 }
@@ -380,6 +386,7 @@ static hipError_t launch_cfg(const GemmParams& p, int epi, int omode, int num_cu
         if (p.R && !p.V && omode == OUT_ROWS && epi == EPI_BIAS) return launch_cfg<MB, NBW, BK, NST, true>(p, epi, omode, num_cus, s);
     }
     constexpr int BM = MB * 16, BN = NBW * 64;
+    static_assert(BM <= ROW_PAD, "whole-tile stores of the last row tile must stay inside the workspace padding");
     static_assert(g4_lds_bytes<MB, NBW, BK, NST>(1024) <= 160 * 1024, "tile does not fit the 160 KiB LDS");
     const size_t lds = g4_lds_bytes<MB, NBW, BK, NST>(p.N);
     static size_t attr_lds = 0;
@@ -433,7 +440,7 @@ int gemm2_num_cus() {
 
 bool gemm2_supported(int omode, int epi, const GemmParams& p) {
     return (omode == OUT_ROWS || omode == OUT_TOKROWS) && (epi == EPI_BIAS || epi == EPI_GELU) && p.K % 32 == 0 && p.N % 64 == 0 && p.N <= 8192 && p.lda % 4 == 0 &&
-           p.ldw % 4 == 0 && (long)(p.M + 128) * p.lda * 4 < (1L << 31) && (long)(p.N + 128) * p.ldw * 4 < (1L << 31) &&
+           p.ldw % 4 == 0 && (long)(p.M + ROW_PAD) * p.lda * 4 < (1L << 31) && (long)(p.N + 128) * p.ldw * 4 < (1L << 31) &&
            // float4 epilogue accesses: rows of C / R / V start on 16-byte boundaries
            p.ldc % 4 == 0 && ((uintptr_t)p.C & 15) == 0 && (!p.R || (p.ldr % 4 == 0 && ((uintptr_t)p.R & 15) == 0)) &&
            (!p.V || (p.ldv % 4 == 0 && ((uintptr_t)p.V & 15) == 0));

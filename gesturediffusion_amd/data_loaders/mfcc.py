@@ -80,7 +80,7 @@ class MfccExtractor:
         x = f32c(signal, "signal").reshape(-1)
         n = x.numel()
         F = self.num_frames(n)
-        rows = F + 128
+        rows = F + _lib.GDX_ROW_PAD                # gdx.h: workspace rows per stage
         work = torch.zeros(rows * (self.Lp + 3 * self.nbp + 64) + F, device=x.device, dtype=torch.float32)
         out = torch.empty(F, self.numcep, device=x.device, dtype=torch.float32)
         lib = _lib.load()

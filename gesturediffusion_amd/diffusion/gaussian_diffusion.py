@@ -14,11 +14,13 @@ Supported configuration = the one the reference hard-codes (`utils/model_util.py
 START_X mean, FIXED_SMALL / FIXED_LARGE variance.  The backward half of training, cond_fn_with_grad and
 learned variances are outside the hot path and raise NotImplementedError.
 
-RNG.  `rng="torch"` (default) draws x_T with `torch.randn` and one `torch.randn_like` per step
-from torch's generator on the sample's device, in the reference's order, so a run is
-reproducible against the reference on the same device and seed.  `rng="philox"` uses the fused
-loop with counter-based noise keyed by (seed, global sample index, step): results do not depend
-on how a batch is sharded over GPUs.  `noise_tape=` replays recorded noise (parity tests).
+RNG.  `rng="torch"` (default) draws x_T with `torch.randn` and one N(0,1) tensor per step from torch's
+generator on the sample's device, in the reference's order (`:694`, `:532`), so a run is reproducible against
+the reference on the same device and seed; the draws are made `NOISE_BLOCK` steps ahead into a tape and the
+loop itself runs inside libgdx (`gdx_sample_loop`, one call per block), so the reference caller's own kwargs
+(`sample/generate.py:119-130`: `progress=True, noise=None`) take the fused path.  `rng="philox"` generates the
+noise inside the update kernel, counter-based and keyed by (seed, global sample index, step): results do not
+depend on how a batch is sharded over GPUs.  `noise_tape=` replays recorded noise (parity tests).
 """
 import enum
 import math
@@ -71,6 +73,9 @@ class LossType(enum.Enum):
 
     def is_vb(self):
         return self == LossType.KL or self == LossType.RESCALED_KL
+
+
+NOISE_BLOCK = 50        # steps of torch-generator noise drawn ahead of one gdx_sample_loop call (rng="torch")
 
 
 def _is_native(model):
@@ -296,16 +301,20 @@ class GaussianDiffusion:
 
     def _loop(self, kind, model, shape, noise, clip_denoised, denoised_fn, cond_fn, model_kwargs, device, progress,
               eta, skip_timesteps, init_image, randomize_class, cond_fn_with_grad, const_noise, rng, philox_seed,
-              sample_offset, noise_tape, dump_steps=None):
+              sample_offset, noise_tape, dump_steps=None, every_step=False):
+        """every_step: the caller consumes each step's dict (the *_progressive generators, or `fused=False`: the
+        step-wise callable protocol model(x, t, **kw) + one gdx_sampler_update per step); otherwise only the final state
+        is needed and the whole loop runs inside libgdx."""
         if cond_fn_with_grad or randomize_class:
             raise NotImplementedError("cond_fn_with_grad / randomize_class are outside the sampling hot path")
+        if rng not in ("torch", "philox"):
+            raise ValueError(f"rng must be 'torch' or 'philox', got {rng!r}")
         device, img, indices = self._prepare_loop(model, shape, noise, device, skip_timesteps, init_image, rng,
                                                   philox_seed, sample_offset, noise_tape)
-        fused = (rng == "philox" or noise_tape is not None) and _is_native(model) and not clip_denoised \
-            and denoised_fn is None and not progress and cond_fn is None
+        fused = not every_step and _is_native(model) and not clip_denoised and denoised_fn is None and cond_fn is None
         if fused:
-            yield from self._fused_loop(kind, model, img, indices, model_kwargs, eta, const_noise, philox_seed,
-                                        sample_offset, noise_tape, dump_steps)
+            yield from self._fused_loop(kind, model, img, indices, model_kwargs, eta, const_noise, rng, philox_seed,
+                                        sample_offset, noise_tape, dump_steps, progress)
             return
         if progress:
             from tqdm.auto import tqdm
@@ -323,9 +332,12 @@ class GaussianDiffusion:
             yield out
             img = out["sample"]
 
-    def _fused_loop(self, kind, model, img, indices, model_kwargs, eta, const_noise, philox_seed, sample_offset,
-                    noise_tape, dump_steps):
-        """Whole loop inside libgdx (gdx_sample_loop); yields only the final state."""
+    def _fused_loop(self, kind, model, img, indices, model_kwargs, eta, const_noise, rng, philox_seed, sample_offset,
+                    noise_tape, dump_steps, progress):
+        """Whole loop inside libgdx (gdx_sample_loop); yields only the final state.  Noise: a recorded tape, in-kernel
+        Philox, or torch's generator -- then one `normal_()` per step in the reference's order (:532: randn_like(x) is
+        empty_like(x).normal_()), drawn NOISE_BLOCK steps ahead into a tape the update kernel reads; the loop is issued
+        block by block with no host synchronisation in between (with `progress` one per block, to report it)."""
         from ..model.cfg_sampler import ClassifierFreeSampleModel
         self._check_supported()
         y = model_kwargs["y"]
@@ -338,7 +350,7 @@ class GaussianDiffusion:
             raise _window_error(T, 10)
         eng = inner._get_engine(x.device)
         eng.prepare(B, T)
-        eng.set_condition(y["seed"], y["mfcc"])
+        eng.set_condition(y["seed"], y["mfcc"], cache=False)
         if isinstance(model, ClassifierFreeSampleModel):
             mode, scale = GDX_CFG, E.f32c(y["scale"].reshape(-1), "y['scale']")
         else:
@@ -347,21 +359,50 @@ class GaussianDiffusion:
         if "inpainting_mask" in y and "inpainted_motion" in y:
             mask = E.require_device(y["inpainting_mask"], "inpainting_mask").to(th.bool).contiguous()
             motion = E.f32c(y["inpainted_motion"], "inpainted_motion")
+            assert mask.shape == motion.shape == x.shape
+        n = len(indices)
         tape = None
         if noise_tape is not None:
-            tape = E.f32c(noise_tape[1:1 + len(indices)], "noise_tape")
+            tape = E.f32c(noise_tape[1:1 + n], "noise_tape")
             if const_noise:
                 tape = tape[:, :1].contiguous()
         tmap = self._timestep_map()
         dump = None
         if dump_steps is not None:
-            dump_steps = sorted(int(s) for s in dump_steps if 0 <= int(s) < len(indices))
+            dump_steps = sorted({int(s) for s in dump_steps if 0 <= int(s) < n})     # `i in dump_steps`: each step once
             dump = th.empty(len(dump_steps), *x.shape, device=x.device, dtype=th.float32)
         if self.rescale_timesteps:
             raise NotImplementedError("rescale_timesteps=True is not used by the reference's sampler configuration")
-        eng.sample_loop(x, kind, mode, self.coef_table(kind, x.device, eta), tmap, indices[0], scale=scale,
-                        inpaint_mask=mask, inpaint_motion=motion, noise_tape=tape, const_noise=const_noise,
-                        philox_seed=philox_seed, sample_offset=sample_offset, dump=dump, dump_steps=dump_steps)
+        draw = tape is None and rng == "torch"
+        block = min(n, NOISE_BLOCK) if (draw or progress) else n
+        bar = None
+        if progress:
+            from tqdm.auto import tqdm
+            bar = tqdm(total=n)
+        coef = self.coef_table(kind, x.device, eta)
+        buf = th.empty((block, 1 if const_noise else B, J, F, T), device=x.device, dtype=th.float32) if draw else None
+        full = th.empty_like(x) if draw and const_noise else None
+        k = 0
+        while k < n:
+            nb = min(block, n - k)
+            if draw:
+                for j in range(nb):
+                    if const_noise:
+                        buf[j].copy_(full.normal_()[:1])      # reference :534-535: the full draw, sample 0 kept
+                    else:
+                        buf[j].normal_()
+                blk = buf
+            else:
+                blk = tape[k:] if tape is not None else None
+            eng.sample_loop(x, kind, mode, coef, tmap, indices[k], scale=scale, inpaint_mask=mask,
+                            inpaint_motion=motion, noise_tape=blk, const_noise=const_noise, philox_seed=philox_seed,
+                            sample_offset=sample_offset, dump=dump, dump_steps=dump_steps, run_steps=nb, k_base=k)
+            k += nb
+            if bar is not None:
+                th.cuda.current_stream(x.device).synchronize()
+                bar.update(nb)
+        if bar is not None:
+            bar.close()
         yield {"sample": x, "pred_xstart": None, "dump": dump, "fused": True}
 
     def _timestep_map(self):
@@ -370,13 +411,13 @@ class GaussianDiffusion:
     def p_sample_loop(self, model, shape, noise=None, clip_denoised=True, denoised_fn=None, cond_fn=None,
                       model_kwargs=None, device=None, progress=False, skip_timesteps=0, init_image=None,
                       randomize_class=False, cond_fn_with_grad=False, dump_steps=None, const_noise=False,
-                      rng="torch", philox_seed=0, sample_offset=0, noise_tape=None):
+                      rng="torch", philox_seed=0, sample_offset=0, noise_tape=None, fused=True):
         final = None
         dump = [] if dump_steps is not None else None
         for i, sample in enumerate(self._loop(GDX_SAMPLER_P, model, shape, noise, clip_denoised, denoised_fn, cond_fn,
                                               model_kwargs, device, progress, 0.0, skip_timesteps, init_image,
                                               randomize_class, cond_fn_with_grad, const_noise, rng, philox_seed,
-                                              sample_offset, noise_tape, dump_steps)):
+                                              sample_offset, noise_tape, dump_steps, every_step=not fused)):
             if sample.get("fused"):
                 if dump_steps is not None:
                     return [d.clone() for d in sample["dump"]]
@@ -393,12 +434,12 @@ class GaussianDiffusion:
                                   randomize_class=False, cond_fn_with_grad=False, const_noise=False):
         yield from self._loop(GDX_SAMPLER_P, model, shape, noise, clip_denoised, denoised_fn, cond_fn, model_kwargs,
                               device, progress, 0.0, skip_timesteps, init_image, randomize_class, cond_fn_with_grad,
-                              const_noise, "torch", 0, 0, None)
+                              const_noise, "torch", 0, 0, None, every_step=True)
 
     def ddim_sample_loop(self, model, shape, noise=None, clip_denoised=True, denoised_fn=None, cond_fn=None,
                          model_kwargs=None, device=None, progress=False, eta=0.0, skip_timesteps=0, init_image=None,
                          randomize_class=False, cond_fn_with_grad=False, dump_steps=None, const_noise=False,
-                         rng="torch", philox_seed=0, sample_offset=0, noise_tape=None):
+                         rng="torch", philox_seed=0, sample_offset=0, noise_tape=None, fused=True):
         if dump_steps is not None:
             raise NotImplementedError()                                   # reference :903-904
         if const_noise == True:  # noqa: E712
@@ -406,7 +447,8 @@ class GaussianDiffusion:
         final = None
         for sample in self._loop(GDX_SAMPLER_DDIM, model, shape, noise, clip_denoised, denoised_fn, cond_fn,
                                  model_kwargs, device, progress, eta, skip_timesteps, init_image, randomize_class,
-                                 cond_fn_with_grad, False, rng, philox_seed, sample_offset, noise_tape):
+                                 cond_fn_with_grad, False, rng, philox_seed, sample_offset, noise_tape,
+                                 every_step=not fused):
             final = sample
         return final["sample"]
 
@@ -416,7 +458,7 @@ class GaussianDiffusion:
                                      cond_fn_with_grad=False):
         yield from self._loop(GDX_SAMPLER_DDIM, model, shape, noise, clip_denoised, denoised_fn, cond_fn,
                               model_kwargs, device, progress, eta, skip_timesteps, init_image, randomize_class,
-                              cond_fn_with_grad, False, "torch", 0, 0, None)
+                              cond_fn_with_grad, False, "torch", 0, 0, None, every_step=True)
 
     # ------------------------------------------------------------------ explicitly out of scope
     def masked_l2(self, a, b, mask):

@@ -52,7 +52,8 @@ class SpacedDiffusion(GaussianDiffusion):
     def _wrap_model(self, model):
         if isinstance(model, _WrappedModel):
             return model
-        return _WrappedModel(model, self.timestep_map, self.rescale_timesteps, self.original_num_steps)
+        return _WrappedModel(model, self.timestep_map, self.rescale_timesteps, self.original_num_steps,
+                             self.__dict__.setdefault("_map_tables", {}))
 
     def _call_model(self, model, x, t, model_kwargs):
         return self._wrap_model(model)(x, t, **model_kwargs)
@@ -67,27 +68,26 @@ class SpacedDiffusion(GaussianDiffusion):
         return t   # scaling is done by the wrapped model
 
 
-_MAP_CACHE = {}
-
-
 class _WrappedModel:
-    def __init__(self, model, timestep_map, rescale_timesteps, original_num_steps):
+    def __init__(self, model, timestep_map, rescale_timesteps, original_num_steps, tables=None):
         self.model = model
         self.timestep_map = timestep_map
         self.rescale_timesteps = rescale_timesteps
         self.original_num_steps = original_num_steps
+        # device copies of the map per (device, dtype); owned by the SpacedDiffusion that built this wrapper (so a
+        # new wrapper per step reuses them) and never shared between diffusions -- two maps of equal length
+        # ("ddim10": 0,100,..,900 vs [10]: 0,111,..,999) must not see each other's table
+        self._tables = tables if tables is not None else {}
 
     def __call__(self, x, ts, **kwargs):
         return self.model(x, self.map_timesteps(ts), **kwargs)
 
     def map_timesteps(self, ts):
-        """Respaced index -> original timestep, looked up on `ts`'s device (table cached per device and dtype)."""
-        key = (id(self.timestep_map), len(self.timestep_map), str(ts.device), ts.dtype)
-        table = _MAP_CACHE.get(key)
+        """Respaced index -> original timestep, looked up on `ts`'s device."""
+        key = (str(ts.device), ts.dtype)
+        table = self._tables.get(key)
         if table is None:
-            if len(_MAP_CACHE) > 64:
-                _MAP_CACHE.clear()
-            table = _MAP_CACHE[key] = th.tensor(self.timestep_map, device=ts.device, dtype=ts.dtype)
+            table = self._tables[key] = th.tensor(self.timestep_map, device=ts.device, dtype=ts.dtype)
         mapped = table[ts]
         if self.rescale_timesteps:
             mapped = mapped.float() * (1000.0 / self.original_num_steps)

@@ -92,17 +92,21 @@ class Engine:
             self.shape = (batch, frames)
             self._cond_key = None
 
-    def set_condition(self, seed, mfcc):
-        """seed [B,J,1,P], mfcc [B,26,1,T]; cached on (pointer, version) so the per-step callable
-        protocol model(x, t, y=...) does not redo the step-invariant work."""
-        key = (seed.data_ptr(), seed._version, tuple(seed.shape), mfcc.data_ptr(), mfcc._version, tuple(mfcc.shape))
-        if key == self._cond_key:
+    def set_condition(self, seed, mfcc, cache=True):
+        """seed [B,J,1,P], mfcc [B,26,1,T].  The step-wise callable protocol model(x, t, y=...) calls this on every
+        step, so the step-invariant work is skipped when the SAME tensors come back: the key is (storage pointer,
+        version counter, shape, strides) and the engine keeps references to the caller's own tensors while the key is
+        live -- their storage can therefore not be freed and handed to a different tensor with an equal key (a view
+        such as sample_out[..., -seed_poses:] shares its base's storage and version counter).  `cache=False` (the
+        fused loop: one call per 1000 steps) always recomputes."""
+        key = tuple((t.data_ptr(), t._version, tuple(t.shape), tuple(t.stride()), t.dtype) for t in (seed, mfcc))
+        if cache and key == self._cond_key:
             return
         seed_c, mfcc_c = f32c(seed, "y['seed']"), f32c(mfcc, "y['mfcc']")
         _lib.check(self.lib.gdx_set_condition(self.handle, _ptr(seed_c), _ptr(mfcc_c), _stream(seed_c.device)),
                    self.lib)
-        self._keep = [seed_c, mfcc_c]
-        self._cond_key = key
+        self._keep = [seed, mfcc, seed_c, mfcc_c]
+        self._cond_key = key if cache else None
 
     # ------------------------------------------------------------------ compute
     def forward(self, x, timesteps, mode=GDX_COND, scale=None):
@@ -118,6 +122,17 @@ class Engine:
         _lib.check(self.lib.gdx_set_keep_taps(self.handle, int(keep)), self.lib)
         self._cond_key = None if keep else self._cond_key
 
+    def set_guards(self, on=True):
+        """Test aid: canary zones behind every workspace buffer (gdx_set_guards)."""
+        _lib.check(self.lib.gdx_set_guards(self.handle, int(bool(on))), self.lib)
+        self.shape = self.shape          # the workspace was re-allocated: conditioning must be set again
+        self._cond_key = None
+
+    def check_guards(self, device):
+        bad, first = C.c_int64(), C.c_int32()
+        _lib.check(self.lib.gdx_check_guards(self.handle, C.byref(bad), C.byref(first), _stream(device)), self.lib)
+        return bad.value, first.value
+
     def tap(self, which, rows, d, device):
         out = torch.empty(rows, d, device=device, dtype=torch.float32)
         _lib.check(self.lib.gdx_get_tap(self.handle, which, _ptr(out), out.numel(), _stream(device)), self.lib)
@@ -125,8 +140,8 @@ class Engine:
 
     def sample_loop(self, x, kind, mode, coef, timestep_map, first_index, scale=None, inpaint_mask=None,
                     inpaint_motion=None, noise_tape=None, const_noise=False, philox_seed=0, sample_offset=0,
-                    dump=None, dump_steps=None):
-        """x is updated in place (x_T in, final sample out)."""
+                    dump=None, dump_steps=None, run_steps=0, k_base=0):
+        """x is updated in place (x_T in, final sample out).  run_steps / k_base: one block of a loop (gdx.h)."""
         tmap = np.ascontiguousarray(np.asarray(timestep_map, dtype=np.int64))
         ds = np.ascontiguousarray(np.asarray(dump_steps if dump_steps is not None else [], dtype=np.int32))
         a = _lib.LoopArgs(kind=kind, mode=mode, num_steps=len(tmap), first_index=first_index, coef=coef.data_ptr(),
@@ -137,7 +152,8 @@ class Engine:
                           noise_tape=noise_tape.data_ptr() if noise_tape is not None else None,
                           const_noise=int(const_noise), philox_seed=philox_seed, sample_offset=sample_offset,
                           dump=dump.data_ptr() if dump is not None else None,
-                          dump_steps=ds.ctypes.data if len(ds) else None, n_dump=len(ds))
+                          dump_steps=ds.ctypes.data if len(ds) else None, n_dump=len(ds), run_steps=run_steps,
+                          k_base=k_base)
         _lib.check(self.lib.gdx_sample_loop(self.handle, C.byref(a), _stream(x.device)), self.lib)
         self._keep_loop = (tmap, ds)
 

@@ -4,7 +4,8 @@
 (`utils/dist_util.py:18-51`).  The reference never initialises a process group (its MPI/NCCL code
 is commented out, `:26-41`); multi-GPU here is new functionality around the hot path: samples of
 a batch are independent, so each rank samples a contiguous shard with zero communication and one
-RCCL gather over xGMI at the end returns the batch to rank 0.
+RCCL gather over xGMI at the end returns the batch to rank 0.  N > 1 has only been
+exercised on CPU (gloo, world size 2) and as several ranks sharing one GPU; RCCL across GPUs is the driver's run.
 """
 import os
 
@@ -60,17 +61,29 @@ def shard_range(total, rank, world):
 
 
 def gather_samples(local, total, dst=0):
-    """End-of-loop gather of per-rank sample shards [b_r, ...] to `dst` (the path's only
-    collective).  Uses all_gather on equal-size padded shards (RCCL over xGMI when on GPU)."""
+    """End-of-loop gather of per-rank sample shards [b_r, ...] to `dst` -- the path's only collective.
+
+    One group of point-to-point transfers: `dst` posts a receive per peer straight into that peer's row range of ONE
+    preallocated [total, ...] buffer (row ranges of a contiguous tensor are contiguous, so nothing is staged, padded or
+    concatenated), every other rank posts one send of its shard.  On GPUs this is an ncclSend / ncclRecv group over the
+    direct xGMI links: `total` samples cross the fabric once and only `dst` holds the full batch (an all_gather moves
+    world x that and materialises it on every rank).  Uneven shards (41 samples over 8 ranks) need no padding; ranks
+    with an empty shard post nothing.  Returns the full batch on `dst`, None elsewhere."""
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return local
     world, rank = dist.get_world_size(), dist.get_rank()
-    sizes = [shard_range(total, r, world) for r in range(world)]
-    maxb = max(hi - lo for lo, hi in sizes)
-    pad = local.new_zeros((maxb,) + tuple(local.shape[1:]))
-    pad[: local.shape[0]] = local
-    bufs = [th.empty_like(pad) for _ in range(world)]
-    dist.all_gather(bufs, pad)
-    if rank != dst:
-        return None
-    return th.cat([b[: hi - lo] for b, (lo, hi) in zip(bufs, sizes)], dim=0)
+    spans = [shard_range(total, r, world) for r in range(world)]
+    lo, hi = spans[rank]
+    if local.shape[0] != hi - lo:
+        raise ValueError(f"rank {rank} holds {local.shape[0]} samples, its shard of {total} is {hi - lo}")
+    full, ops = None, []
+    if rank == dst:
+        full = local.new_empty((total,) + tuple(local.shape[1:]))
+        full[lo:hi].copy_(local)
+        ops = [dist.P2POp(dist.irecv, full[a:b], r) for r, (a, b) in enumerate(spans) if r != dst and b > a]
+    elif hi > lo:
+        ops = [dist.P2POp(dist.isend, local.contiguous(), dst)]
+    if ops:
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+    return full

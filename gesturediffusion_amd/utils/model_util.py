@@ -12,56 +12,59 @@ from ..model.mdm import MDM
 from ..model.mdm_old import MDM_Old
 
 
+DIFFUSION_STEPS = 1000          # fixed: the reference parses --diffusion_steps and then ignores it (utils/model_util.py:40)
+
+
+def load_checkpoint(path):
+    """A `model#########.pt` written by the reference's trainer (`train/training_loop.py:265-285`: a plain
+    `torch.save(state_dict)` without the CLIP weights).  Loaded with `weights_only=True`: nothing in the file executes."""
+    import torch
+    return torch.load(path, map_location="cpu", weights_only=True)
+
+
 def load_model_wo_clip(model, state_dict):
-    missing_keys, unexpected_keys = model.load_state_dict(state_dict, strict=False)
-    assert len(unexpected_keys) == 0
-    assert all([k.startswith('clip_model.') for k in missing_keys])
+    """Non-strict load with the reference's two guarantees (`utils/model_util.py:6-9`, both AssertionError): the checkpoint
+    holds no key the model does not know, and only CLIP weights may be absent from it."""
+    outcome = model.load_state_dict(state_dict, strict=False)
+    assert not outcome.unexpected_keys, f"unexpected keys in checkpoint: {outcome.unexpected_keys[:5]}"
+    stray = [k for k in outcome.missing_keys if not k.startswith("clip_model.")]
+    assert not stray, f"checkpoint lacks non-CLIP parameters: {stray[:5]}"
 
 
 def create_model_and_diffusion(args, data=None):
     cls = MDM_Old if getattr(args, "arch_version", "mdm") == "mdm_old" else MDM
     model = cls(**get_model_args(args, data), compute_dtype=getattr(args, "compute_dtype", None))
-    diffusion = create_gaussian_diffusion(args)
-    return model, diffusion
+    return model, create_gaussian_diffusion(args)
 
 
 def get_model_args(args, data=None):
-    clip_version = 'ViT-B/32'
-    if args.dataset in ['genea2022', 'genea2023']:
-        data_rep, njoints, nfeats = 'genea_vec', 498, 1
+    """Constructor keywords of MDM / MDM_Old.  The key set is the contract with `MDM.__init__(**kargs)`
+    (`utils/model_util.py:18-34`); everything not taken from `args` is a constant there too."""
+    if args.dataset in ("genea2022", "genea2023"):
+        njoints = 498                                    # 83 joints x (3 rotation + 3 position) features
     elif getattr(args, "synthetic_njoints", None):
-        # additive: synthetic shapes for benchmarking (HumanML3D 263, HumanAct12 25x6=150 flattened)
-        data_rep, njoints, nfeats = 'genea_vec', int(args.synthetic_njoints), 1
+        njoints = int(args.synthetic_njoints)            # additive: synthetic shapes (HumanML3D 263, HumanAct12 150)
     else:
-        raise UnboundLocalError("local variable 'data_rep' referenced before assignment")  # as the reference
-    return {'modeltype': '', 'njoints': njoints, 'nfeats': nfeats, 'translation': True, 'pose_rep': 'rot6d',
-            'glob': True, 'glob_rot': True, 'latent_dim': args.latent_dim, 'ff_size': 1024,
-            'num_layers': args.layers, 'num_heads': 4, 'dropout': 0.1, 'activation': "gelu", 'data_rep': data_rep,
-            'cond_mask_prob': args.cond_mask_prob, 'clip_version': clip_version, 'dataset': args.dataset,
-            'use_text': args.use_text, 'mfcc_input': args.mfcc_input, 'use_wav_enc': args.use_wav_enc,
-            'seed_poses': args.seed_poses, 'use_audio': args.use_audio}
+        # the reference falls off its if-chain with data_rep unbound; same exception class for callers that catch it
+        raise UnboundLocalError("local variable 'data_rep' referenced before assignment")
+    fixed = dict(modeltype="", nfeats=1, translation=True, pose_rep="rot6d", glob=True, glob_rot=True, ff_size=1024,
+                 num_heads=4, dropout=0.1, activation="gelu", data_rep="genea_vec", clip_version="ViT-B/32")
+    from_args = dict(njoints=njoints, latent_dim=args.latent_dim, num_layers=args.layers,
+                     cond_mask_prob=args.cond_mask_prob, dataset=args.dataset, use_text=args.use_text,
+                     mfcc_input=args.mfcc_input, use_wav_enc=args.use_wav_enc, seed_poses=args.seed_poses,
+                     use_audio=args.use_audio)
+    return {**fixed, **from_args}
 
 
 def create_gaussian_diffusion(args):
-    predict_xstart = True
-    steps = 1000
-    scale_beta = 1.0
-    timestep_respacing = getattr(args, "timestep_respacing", '') or ''
-    learn_sigma = False
-    rescale_timesteps = False
-    betas = gd.get_named_beta_schedule(args.noise_schedule, steps, scale_beta)
-    loss_type = gd.LossType.MSE
-    if not timestep_respacing:
-        timestep_respacing = [steps]
-    return SpacedDiffusion(
-        use_timesteps=space_timesteps(steps, timestep_respacing),
-        betas=betas,
-        model_mean_type=(gd.ModelMeanType.EPSILON if not predict_xstart else gd.ModelMeanType.START_X),
-        model_var_type=((gd.ModelVarType.FIXED_LARGE if not args.sigma_small else gd.ModelVarType.FIXED_SMALL)
-                        if not learn_sigma else gd.ModelVarType.LEARNED_RANGE),
-        loss_type=loss_type,
-        rescale_timesteps=rescale_timesteps,
-        lambda_vel=args.lambda_vel,
-        lambda_rcxyz=args.lambda_rcxyz,
-        lambda_fc=args.lambda_fc,
-    )
+    """The single sampler configuration the reference builds (`utils/model_util.py:37-72`): the network predicts x_0,
+    the reverse variance is fixed (the posterior variance unless `sigma_small` is falsy, then beta), the loss is plain
+    MSE, timesteps are passed to the model unscaled, and the schedule has 1000 steps.  `args.timestep_respacing` is
+    additive (the reference hard-codes ''): '' keeps every step."""
+    respacing = getattr(args, "timestep_respacing", "") or [DIFFUSION_STEPS]
+    variance = gd.ModelVarType.FIXED_SMALL if args.sigma_small else gd.ModelVarType.FIXED_LARGE
+    return SpacedDiffusion(use_timesteps=space_timesteps(DIFFUSION_STEPS, respacing),
+                           betas=gd.get_named_beta_schedule(args.noise_schedule, DIFFUSION_STEPS),
+                           model_mean_type=gd.ModelMeanType.START_X, model_var_type=variance,
+                           loss_type=gd.LossType.MSE, rescale_timesteps=False, lambda_vel=args.lambda_vel,
+                           lambda_rcxyz=args.lambda_rcxyz, lambda_fc=args.lambda_fc)

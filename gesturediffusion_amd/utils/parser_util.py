@@ -7,49 +7,44 @@ dataset / model / diffusion groups are overwritten from `args.json` next to the 
 non-empty string (`:55,67`), `--dataset`'s default is outside its own choices (`:101`).
 Additive flags live in the 'native' group and never collide with reference names.
 """
-import argparse
 import json
 import os
 from argparse import ArgumentParser
 
 
+CHECKPOINT_GROUPS = ("dataset", "model", "diffusion")     # option groups a checkpoint's args.json decides (:13)
+
+
 def parse_and_load_from_model(parser, argv=None):
-    add_data_options(parser)
-    add_model_options(parser)
-    add_diffusion_options(parser)
-    add_native_options(parser)
+    """Parse the command line, then let the `args.json` stored next to the checkpoint decide every option of the
+    dataset / model / diffusion groups (reference `utils/parser_util.py:7-33`): a model is sampled with the settings it
+    was trained with, whatever the command line says.  Options the file does not know keep their value, with the
+    reference's warning.  A model trained without condition dropout cannot be guided, so its guidance scale becomes 1."""
+    for add in (add_data_options, add_model_options, add_diffusion_options, add_native_options):
+        add(parser)
     args = parser.parse_args(argv)
-    args_to_overwrite = []
-    for group_name in ['dataset', 'model', 'diffusion']:
-        args_to_overwrite += get_args_per_group_name(parser, args, group_name)
-
-    if args.synthetic and not args.model_path:
-        # additive: no checkpoint on disk, random weights of the requested architecture
-        if args.cond_mask_prob == 0:
-            args.guidance_param = 1
-        return args
-
-    model_path = args.model_path
-    args_path = os.path.join(os.path.dirname(model_path), 'args.json')
-    assert os.path.exists(args_path), 'Arguments json file was not found!'
-    with open(args_path, 'r') as fr:
-        model_args = json.load(fr)
-    for a in args_to_overwrite:
-        if a in model_args.keys():
-            setattr(args, a, model_args[a])
-        else:
-            print('Warning: was not able to load [{}], using default value [{}] instead.'.format(a, args.__dict__[a]))
+    if not (args.synthetic and not args.model_path):     # additive: --synthetic without a checkpoint has no args.json
+        stored_path = os.path.join(os.path.dirname(args.model_path), "args.json")
+        assert os.path.exists(stored_path), "Arguments json file was not found!"
+        with open(stored_path) as f:
+            stored = json.load(f)
+        for name in (n for title in CHECKPOINT_GROUPS for n in get_args_per_group_name(parser, args, title)):
+            if name in stored:
+                setattr(args, name, stored[name])
+            else:
+                print("Warning: was not able to load [{}], using default value [{}] instead.".format(name, getattr(args, name)))
     if args.cond_mask_prob == 0:
         args.guidance_param = 1
     return args
 
 
 def get_args_per_group_name(parser, args, group_name):
+    """Destination names of the options declared in the argparse group titled `group_name`.  (The reference *returns* a
+    ValueError instance for an unknown title instead of raising it, `:36-41`; iterating that fails with TypeError -- kept.)"""
     for group in parser._action_groups:
         if group.title == group_name:
-            group_dict = {a.dest: getattr(args, a.dest, None) for a in group._group_actions}
-            return list(argparse.Namespace(**group_dict).__dict__.keys())
-    return ValueError('group_name was not found.')
+            return [action.dest for action in group._group_actions]
+    return ValueError("group_name was not found.")
 
 
 def add_base_options(parser):
@@ -125,8 +120,10 @@ def add_native_options(parser):
                        help="p_sample_loop (reference default) or ddim_sample_loop.")
     group.add_argument("--timestep_respacing", default='', type=str, help="e.g. ddim100; '' = all 1000 steps.")
     group.add_argument("--eta", default=0.0, type=float)
-    group.add_argument("--rng", default='torch', choices=['torch', 'philox'],
-                       help="torch = reference draw order; philox = fused in-kernel noise (shard invariant).")
+    group.add_argument("--rng", default=None, choices=['torch', 'philox'],
+                       help="torch = the reference's generator and draw order (single-GPU default); philox = in-kernel "
+                            "counter-based noise keyed by the global sample index (shard invariant; multi-GPU default).")
+    group.add_argument("--progress", action='store_true', help="tqdm bar over the denoising steps (reference: always on).")
     group.add_argument("--chunks", default=14, type=int, help="Autoregressive chunks per take (reference: 14).")
     group.add_argument("--synthetic_audio", action='store_true',
                        help="With --synthetic: derive y['mfcc'] from synthetic audio through the GPU MFCC front end "

@@ -26,6 +26,10 @@ extern "C" {
 
 typedef struct gdx_model* gdx_handle_t;
 
+/* Rows of padding the library keeps behind every token-major buffer (its kernels read / store whole tiles); part of
+ * the ABI only through gdx_mfcc's caller-provided workspace layout. */
+#define GDX_ROW_PAD 256
+
 enum { GDX_ARCH_MDM_OLD = 1,  /* model/mdm_old.py:11  MDM_Old ("V1") */
        GDX_ARCH_MDM = 2 };    /* model/mdm.py:10      MDM     ("V2") */
 
@@ -99,6 +103,12 @@ int gdx_forward(gdx_handle_t h, const float* x, const int64_t* timesteps, int32_
  * forward's last layer buffer is live unless keep_taps was set), see gdx_set_keep_taps. */
 int gdx_set_keep_taps(gdx_handle_t h, int32_t keep);
 int gdx_get_tap(gdx_handle_t h, int32_t which, float* out, int64_t count, void* stream);
+
+/* Test aid: with guards on, every workspace buffer gdx_prepare allocates is followed by a 64 KiB canary zone;
+ * gdx_check_guards synchronises `stream` and counts canary bytes that were overwritten (0 = no kernel stored past
+ * a buffer).  first_bad_zone (optional) = allocation order index of the first damaged zone, -1 if none. */
+int gdx_set_guards(gdx_handle_t h, int32_t on);
+int gdx_check_guards(gdx_handle_t h, int64_t* bad_bytes, int32_t* first_bad_zone, void* stream);
 
 /* ---- sampler update -------------------------------------------------------------------- */
 /* One fused reverse-process update over [B,J,1,T] (replaces p_mean_variance's tail + p_sample /
@@ -196,7 +206,7 @@ int gdx_postprocess(const float* x, const double* mean, const double* std, float
  * (python_speech_features.mfcc(signal, winlen=0.06, winstep=1/fps, samplerate=sr, numcep=27, nfft=5000) and the z-score):
  * pre-emphasis + rectangular framing, power spectrum by a DFT-as-GEMM on the fp32 MFMA kernel, mel filterbank (GEMM),
  * log, DCT-II (ortho), sinusoidal lifter, log frame energy in coefficient 0, (m - mean) / std.
- * signal [n] fp32 (device); tables and workspace as laid out at the definition (csrc/api.hip); mean / std [numcep] or
+ * signal [n] fp32 (device); tables and workspace ((numframes + GDX_ROW_PAD) rows per stage) as laid out at the definition (csrc/api.hip); mean / std [numcep] or
  * NULL; out [numframes][numcep] fp32.  The package is absent from this image: parity with it is UNPINNED
  * (oracle/mfcc.py restates its published algorithm). */
 int gdx_mfcc(const float* signal, int64_t n, int32_t frame_len, int32_t frame_step, int32_t numframes,
@@ -226,8 +236,15 @@ typedef struct {
     uint64_t philox_seed;
     uint64_t sample_offset;
     float* dump;               /* NULL or [n_dump][B,J,1,T] */
-    const int32_t* dump_steps; /* HOST, ascending executed-step numbers */
+    const int32_t* dump_steps; /* HOST, ascending executed-step numbers (counted from the start of the whole loop) */
     int32_t n_dump;
+    /* Running a loop in blocks (the caller draws the noise of one block at a time from torch's generator, the
+     * reference's RNG: gaussian_diffusion.py:532,694; or reports progress per block): this call executes `run_steps`
+     * steps starting at index first_index (0 = all the way down to index 0), and the first of them is executed-step
+     * number `k_base` of the whole loop (Philox draw number k_base + 1; dump_steps compare against it).  noise_tape
+     * always starts at THIS call's first step. */
+    int32_t run_steps;
+    int32_t k_base;
 } gdx_loop_args_t;
 int gdx_sample_loop(gdx_handle_t h, const gdx_loop_args_t* a, void* stream);
 

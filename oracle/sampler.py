@@ -154,6 +154,22 @@ def plms_loop(model_fn, tab, tmap, shape, x_T, y, order=2, skip_timesteps=0, ini
 
 
 # ---------------------------------------------------------------------------------------------
+def sample_chunks(model_fn, tab, tmap, first_seed, mfccs, tapes, seed_poses, scale=None, kind="p", eta=0.0):
+    """The chunked autoregressive driver, reference sample/generate.py:91-130: chunk c is one whole sampling loop whose
+    y['seed'] is `first_seed` for c = 0 and afterwards the last `seed_poses` frames of chunk c-1's output (:104-107);
+    y['scale'] = ones * guidance_param when guidance is on (:114-115).  tapes[c] = [x_T, z_0, ...] of chunk c.
+    Pinned by tests/golden/chunks_tiny.npz (the reference's own p_sample_loop + ClassifierFreeSampleModel driven through
+    these statements)."""
+    outs, sample_out = [], None
+    for c, (mfcc, tape) in enumerate(zip(mfccs, tapes)):
+        y = {"mfcc": mfcc, "seed": first_seed if c == 0 else sample_out[..., -seed_poses:]}
+        if scale is not None:
+            y["scale"] = torch.ones(first_seed.shape[0]) * scale
+        sample_out = sample_loop(model_fn, tab, tmap, tuple(tape[0].shape), tape, y, kind=kind, eta=eta)
+        outs.append(sample_out)
+    return outs
+
+
 def postprocess_chunk(sample_out, mean, std):
     """Tail of the reference's chunk loop, sample/generate.py:132-146 (rot2xyz with pose_rep 'xyz' is the identity):
     inv_transform on [B, 1, T, J] (torch fp32 * numpy fp64 statistics -> fp64, then .float()), then the position /

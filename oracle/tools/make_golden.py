@@ -360,6 +360,51 @@ def gen_losses_tiny(mods, out):
         np.savez_compressed(os.path.join(out, f"losses_{arch}_tiny.npz"), **d)
 
 
+CHUNKS = dict(njoints=18, n_chunks=3, B=3, T=20, respacing=[20], scale=2.5, tape_seed=4321)
+
+
+def chunk_inputs(cfg=None):
+    """Inputs of the chunked-driver fixture, regenerated identically by the generator and the tests: weights, first seed
+    poses, per-chunk MFCCs and per-chunk noise tapes (x_T + one draw per step)."""
+    c = CHUNKS
+    cfg = cfg or dict(TINY, arch="mdm", njoints=c["njoints"])
+    sd = init_state_dict(cfg, seed=6, perturb=True)
+    _, seedp, _ = synthetic_inputs(cfg, c["B"], c["T"], seed=8)
+    g = torch.Generator().manual_seed(c["tape_seed"])
+    mfccs = [torch.randn(c["B"], 26, 1, c["T"], generator=g) for _ in range(c["n_chunks"])]
+    tapes = [torch.randn(c["respacing"][0] + 1, c["B"], c["njoints"], 1, c["T"], generator=g) for _ in range(c["n_chunks"])]
+    return cfg, sd, seedp, mfccs, tapes
+
+
+def gen_chunks_tiny(mods, out):
+    """the reference's chunk loop (`sample/generate.py:91-130`) is three statements around its own
+    `p_sample_loop` -- build y for the chunk, replace y['seed'] by `sample_out[..., -seed_poses:]` after the first chunk
+    (`:104-107`), add the guidance scale (`:114-115`).  `sample/generate.py` itself cannot be imported (bvhsdk, the GENEA
+    dataset), so those three statements are restated here, harness-side, around the REFERENCE's ClassifierFreeSampleModel
+    and p_sample_loop; the outputs pin the build's `sample_chunks` driver (seed hand-off through a non-contiguous view,
+    conditioning re-encoded per chunk)."""
+    ref_cfg, gd, rs = mods[2], mods[3], mods[4]
+    c = CHUNKS
+    d = {}
+    for arch in ("mdm", "mdm_old"):
+        cfg, sd, seedp, mfccs, tapes = chunk_inputs(dict(TINY, arch=arch, njoints=c["njoints"]))
+        model = ref_cfg.ClassifierFreeSampleModel(build_ref_model(mods, cfg, sd))
+        df = make_diffusion(gd, rs, c["respacing"])
+        shape = (c["B"], c["njoints"], 1, c["T"])
+        sample_out = None
+        for chunk in range(c["n_chunks"]):
+            y = {"mfcc": mfccs[chunk], "seed": seedp}
+            if chunk > 0:
+                y["seed"] = sample_out[..., -cfg["seed_poses"]:]
+            y["scale"] = torch.ones(c["B"]) * c["scale"]
+            with TapeNoise(tapes[chunk][1:]):
+                sample_out = df.p_sample_loop(model, shape, clip_denoised=False, model_kwargs={"y": y}, skip_timesteps=0,
+                                              init_image=None, progress=False, dump_steps=None,
+                                              noise=tapes[chunk][0].clone(), const_noise=False)
+            d[f"{arch}.chunk{chunk}"] = sample_out.numpy()
+    np.savez_compressed(os.path.join(out, "chunks_tiny.npz"), **d)
+
+
 def gen_real_shapes(mods, out):
     """F4: outputs only; weights/inputs regenerate from gesturediffusion_amd.utils.init."""
     cases = {
@@ -469,13 +514,13 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--ref", default="/root/reference")
     ap.add_argument("--out", default=os.path.join(REPO, "tests", "golden"))
-    ap.add_argument("--only", default="", help="comma-separated subset: schedule,forward,loops,plms,losses,guided,collate,real,negative,keys")
+    ap.add_argument("--only", default="", help="comma-separated subset: schedule,forward,loops,plms,losses,guided,collate,chunks,real,negative,keys")
     args = ap.parse_args()
     os.makedirs(args.out, exist_ok=True)
     torch.set_num_threads(8)
     mods = import_reference(args.ref)
     gens = {"schedule": gen_schedule, "forward": gen_forward_tiny, "loops": gen_loops_tiny, "plms": gen_plms_tiny, "losses": gen_losses_tiny, "guided": gen_guided_tiny,
-            "collate": gen_collate, "real": gen_real_shapes, "negative": gen_negative, "keys": gen_state_dict_keys}
+            "collate": gen_collate, "chunks": gen_chunks_tiny, "real": gen_real_shapes, "negative": gen_negative, "keys": gen_state_dict_keys}
     for name in (args.only.split(",") if args.only else gens):
         gens[name](mods, args.out)
     for f in sorted(os.listdir(args.out)):

@@ -1,0 +1,278 @@
+"""Round-2 parity tests (need an MI355X): the drop-in seam with the reference caller's own kwargs, the conditioning
+cache, workspace bounds, the BASELINE configs at their full per-GPU sizes, the chunk driver, checkpoints, sharding."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import REPO, load_golden, rel_err
+from test_gpu_parity import FWD_TOL, LOOP_TOL, TINY, _diffusion, _real_cfg, build_model, dev
+
+pytestmark = pytest.mark.gpu
+F16_TOL = 2e-2
+
+
+# ------------------------------------------------------------------------------------------------ workspace bounds
+@pytest.mark.parametrize("arch,B,T", [("mdm", 4, 270), ("mdm_old", 4, 342), ("mdm", 6, 180), ("mdm", 40, 10), ("mdm_old", 7, 5)])
+def test_whole_tile_stores_stay_inside_the_workspace(arch, B, T):
+    """The persistent GEMM stores whole tiles; with classifier-free guidance M = 2B*S fills the token buffers, and the
+    cost model picks 144-row tiles for these shapes (overshoot up to 143 rows).  Every workspace buffer carries a canary
+    zone (gdx_set_guards): none may be touched, and the result must still match the oracle.  Small T stresses the
+    token-row map of the input linear (rows shifted by the sample index)."""
+    from gesturediffusion_amd.model.cfg_sampler import ClassifierFreeSampleModel
+    from gesturediffusion_amd.utils.init import init_state_dict, synthetic_inputs
+    from oracle import mdm_forward as omf
+    cfg = dict(arch=arch, njoints=263, nfeats=1, latent_dim=512, ff_size=1024, num_layers=2, num_heads=4, seed_poses=10)
+    sd = init_state_dict(cfg, seed=0)
+    m = build_model(arch, cfg, sd)
+    d = dev()
+    eng = m._get_engine(d)
+    eng.set_guards(True)
+    try:
+        x, seedp, mfcc = synthetic_inputs(cfg, B, T, seed=10)
+        t = torch.full((B,), 500, device=d)
+        scale = torch.full((B,), 2.5)
+        y = {"seed": seedp.to(d), "mfcc": mfcc.to(d), "scale": scale.to(d)}
+        out = ClassifierFreeSampleModel(m)(x.to(d), t, y)
+        bad, zone = eng.check_guards(d)
+        assert bad == 0, f"{bad} canary bytes overwritten, first in workspace allocation #{zone}"
+        with torch.no_grad():
+            want = omf.cfg_forward(sd, cfg, x[:2], torch.full((2,), 500), {"seed": seedp[:2], "mfcc": mfcc[:2], "scale": scale[:2]})
+        assert rel_err(out[:2].cpu(), want) < FWD_TOL
+    finally:
+        eng.set_guards(False)
+
+
+# ------------------------------------------------------------------------------------------------ the drop-in seam
+def _count_fused(monkeypatch):
+    from gesturediffusion_amd.engine import Engine
+    calls = {"loop": 0, "forward": 0}
+    orig_loop, orig_fwd = Engine.sample_loop, Engine.forward
+
+    def loop(self, *a, **k):
+        calls["loop"] += 1
+        return orig_loop(self, *a, **k)
+
+    def fwd(self, *a, **k):
+        calls["forward"] += 1
+        return orig_fwd(self, *a, **k)
+    monkeypatch.setattr(Engine, "sample_loop", loop)
+    monkeypatch.setattr(Engine, "forward", fwd)
+    return calls
+
+
+@pytest.mark.parametrize("arch", ["mdm", "mdm_old"])
+@pytest.mark.parametrize("case", ["p", "p_cfg", "p_const_noise", "p_dump", "ddim_eta05", "p_init_skip"])
+def test_reference_callers_kwargs_take_the_fused_loop_and_match_stepwise(arch, case, monkeypatch):
+    """`sample/generate.py:119-130` calls p_sample_loop(model, shape, clip_denoised=False, model_kwargs=..., skip_timesteps=0,
+    init_image=None, progress=True, dump_steps=None, noise=None, const_noise=False): torch's generator, a progress bar.
+    With exactly those kwargs the loop must run inside libgdx (gdx_sample_loop, no per-step model call) and give the bits
+    of the step-wise seam (model(x, t, **kw) + one update per step, randn_like per step) under the same fixseed.
+    120 steps = three noise blocks (50 + 50 + 20)."""
+    from gesturediffusion_amd.model.cfg_sampler import ClassifierFreeSampleModel
+    from gesturediffusion_amd.utils.fixseed import fixseed
+    from gesturediffusion_amd.utils.init import init_state_dict, synthetic_inputs
+    cfg = dict(TINY, arch=arch)
+    m = build_model(arch, cfg, init_state_dict(cfg, seed=3, perturb=True))
+    d = dev()
+    B, T = 3, 20
+    _, seedp, mfcc = synthetic_inputs(cfg, B, T, seed=5)
+    y = {"seed": seedp.to(d), "mfcc": mfcc.to(d)}
+    model = m
+    kw = dict(clip_denoised=False, model_kwargs={"y": y}, skip_timesteps=0, init_image=None, noise=None)
+    df = _diffusion([120])
+    fn = df.p_sample_loop
+    if case == "p_cfg":
+        y["scale"] = torch.tensor([2.5, 1.0, 0.0], device=d)
+        model = ClassifierFreeSampleModel(m)
+    if case == "p_const_noise":
+        kw["const_noise"] = True
+    if case == "p_dump":
+        kw["dump_steps"] = [0, 49, 50, 50, 119]          # a duplicate and both sides of a block boundary
+    if case == "ddim_eta05":
+        fn = df.ddim_sample_loop
+        kw["eta"] = 0.5
+    if case == "p_init_skip":
+        kw.update(init_image=torch.randn(B, TINY["njoints"], 1, T, device=d), skip_timesteps=33)
+    calls = _count_fused(monkeypatch)
+    fixseed(11)
+    fused = fn(model, (B, TINY["njoints"], 1, T), progress=True, **kw)
+    assert calls["forward"] == 0 and calls["loop"] == (2 if case == "p_init_skip" else 3), calls
+    fixseed(11)
+    stepwise = fn(model, (B, TINY["njoints"], 1, T), progress=False, fused=False, **kw)
+    assert calls["forward"] == 120 - (33 if case == "p_init_skip" else 0)
+    if case == "p_dump":
+        assert len(fused) == len(stepwise) == 4
+        fused, stepwise = torch.stack(fused), torch.stack(stepwise)
+    assert torch.isfinite(fused).all() and torch.equal(fused, stepwise)
+
+
+def test_condition_cache_does_not_alias_freed_views():
+    """The reference hands chunk c+1 the seed poses as a non-contiguous VIEW of chunk c's output
+    (`sample/generate.py:104-107`).  Two requests whose views have the same address, version counter, shape and strides
+    but different contents must each be encoded: the step-wise cache may not serve request 2 from request 1's entry once
+    request 1's tensors are gone (the caching allocator hands the same block out again)."""
+    from gesturediffusion_amd.utils.init import init_state_dict, synthetic_inputs
+    from oracle import mdm_forward as omf
+    cfg = dict(TINY, arch="mdm_old")
+    sd = init_state_dict(cfg, seed=3, perturb=True)
+    m = build_model("mdm_old", cfg, sd)
+    d = dev()
+    B, T, P = 2, 20, cfg["seed_poses"]
+    x, _, mfcc = synthetic_inputs(cfg, B, T, seed=5)
+    xd, md, t = x.to(d), mfcc.to(d), torch.tensor([3, 700], device=d)
+    g = torch.Generator().manual_seed(0)
+    outs, ptrs, hosts = [], [], []
+    for req in range(3):
+        prev = torch.randn(B, cfg["njoints"], 1, 64, generator=g)      # "the previous chunk's output"
+        hosts.append(prev[..., -P:].clone())
+        prev_d = prev.to(d)
+        seed_view = prev_d[..., -P:]                                     # non-contiguous view, version 0
+        assert not seed_view.is_contiguous()
+        ptrs.append(seed_view.data_ptr())
+        outs.append(m(xd, t, {"seed": seed_view, "mfcc": md}).cpu())
+        del prev_d, seed_view                                            # request over: its tensors are released
+    for req in range(3):
+        with torch.no_grad():
+            want = omf.forward(sd, cfg, x, t.cpu(), {"seed": hosts[req], "mfcc": mfcc})
+        assert rel_err(outs[req], want) < FWD_TOL, (req, ptrs)
+    assert not torch.equal(outs[0], outs[1]) and not torch.equal(outs[1], outs[2])
+
+
+# ------------------------------------------------------------------------------------------------ full-size configs
+def test_config5_fp16_per_gpu_share_rows_match_single_sample_and_oracle():
+    """BASELINE config 5 at its per-GPU share (V2, J=498, d=1024, T=520, fp16 mode, B=16 = 128 / 8 GPUs): the kernels this
+    size selects (256x256 fp16 GEMM tiles, the 8-wave x 2-block attention) inside a whole forward.  B=1 is pinned to the
+    reference's golden output (`test_fp16_real_shapes`); here every checked row of the B=16 batch must agree with the same
+    sample run alone, and one row with the fp32 CPU oracle, within the fp16 tolerance 2e-2 of max|ref|."""
+    from gesturediffusion_amd.utils.init import init_state_dict, synthetic_inputs
+    from oracle import mdm_forward as omf
+    cfg = _real_cfg("mdm", 498, 1024)
+    sd = init_state_dict(cfg, seed=0)
+    m = build_model("mdm", cfg, sd)
+    m.compute_dtype = "fp16"
+    d = dev()
+    B, T = 16, 520
+    x, seedp, mfcc = synthetic_inputs(cfg, B, T, seed=10)
+    t = torch.full((B,), 500, device=d)
+    full = m(x.to(d), t, {"seed": seedp.to(d), "mfcc": mfcc.to(d)})
+    assert torch.isfinite(full).all()
+    for b in (0, 7, 15):
+        one = m(x[b:b + 1].to(d), t[:1], {"seed": seedp[b:b + 1].to(d), "mfcc": mfcc[b:b + 1].to(d)})
+        assert rel_err(full[b:b + 1].cpu(), one.cpu()) < F16_TOL, b
+    with torch.no_grad():
+        want = omf.forward(sd, cfg, x[7:8], torch.full((1,), 500), {"seed": seedp[7:8], "mfcc": mfcc[7:8]})
+    assert rel_err(full[7:8].cpu(), want) < F16_TOL
+
+
+def test_config3_ddim100_cfg_batch256_rows_equal_small_batch():
+    """BASELINE config 3 (classifier-free guidance, 100-step DDIM, B=256 -> 512 model rows per step): the last 4 steps of
+    the ddim100 loop at the full batch; rows 200..201 must equal, bit for bit, the same two samples run as a batch of 2
+    (counter-based noise keyed by the global sample index, so the initial q_sample noise is the same)."""
+    from gesturediffusion_amd.model.cfg_sampler import ClassifierFreeSampleModel
+    from gesturediffusion_amd.utils.init import init_state_dict, synthetic_inputs
+    cfg = _real_cfg("mdm_old", 263, 512)
+    m = ClassifierFreeSampleModel(build_model("mdm_old", cfg, init_state_dict(cfg, seed=0)))
+    d = dev()
+    B, T, lo = 256, 196, 200
+    _, seedp, mfcc = synthetic_inputs(cfg, B, T, seed=10)
+    df = _diffusion("ddim100")
+
+    def run(sl, off):
+        n = sl.stop - sl.start
+        y = {"seed": seedp[sl].to(d), "mfcc": mfcc[sl].to(d), "scale": torch.full((n,), 2.5, device=d)}
+        return df.ddim_sample_loop(m, (n, 263, 1, T), clip_denoised=False, model_kwargs={"y": y}, skip_timesteps=96,
+                                   rng="philox", philox_seed=10, sample_offset=off)
+    full = run(slice(0, B), 0)
+    assert torch.isfinite(full).all()
+    assert torch.equal(full[lo:lo + 2], run(slice(lo, lo + 2), lo))
+
+
+# ------------------------------------------------------------------------------------------------ N1: chunk driver
+@pytest.mark.parametrize("arch", ["mdm", "mdm_old"])
+@pytest.mark.parametrize("dtype,tol", [("fp32", LOOP_TOL), ("fp16", F16_TOL)])
+def test_chunk_driver_vs_reference_golden(arch, dtype, tol):
+    """`sample_chunks` (the CLI's driver) -- three chunks, guidance 2.5, seed poses handed over as a view of
+    the previous chunk's output on the device -- against the reference's own p_sample_loop + ClassifierFreeSampleModel
+    chained the same way with the same noise tapes (tests/golden/chunks_tiny.npz)."""
+    sys.path.insert(0, os.path.join(REPO, "oracle", "tools"))
+    from make_golden import CHUNKS, TINY as GT, chunk_inputs
+    from gesturediffusion_amd.model.cfg_sampler import ClassifierFreeSampleModel
+    from gesturediffusion_amd.sample.generate import sample_chunks
+    g = load_golden("chunks_tiny.npz")
+    cfg, sd, seedp, mfccs, tapes = chunk_inputs(dict(GT, arch=arch, njoints=CHUNKS["njoints"]))
+    inner = build_model(arch, cfg, sd)
+    inner.compute_dtype = dtype
+    d = dev()
+    outs = sample_chunks(ClassifierFreeSampleModel(inner), _diffusion(CHUNKS["respacing"]), seedp.to(d),
+                         lambda c: mfccs[c].to(d), CHUNKS["n_chunks"], CHUNKS["T"], cfg["seed_poses"],
+                         guidance_param=CHUNKS["scale"], noise_tapes=[t.to(d) for t in tapes])
+    for c, o in enumerate(outs):
+        assert rel_err(o.cpu(), g[f"{arch}.chunk{c}"]) < tol, c
+
+
+# ------------------------------------------------------------------------------------------------ N2: checkpoints
+def test_checkpoint_roundtrip_vs_oracle(tmp_path):
+    """a checkpoint written the way the reference's trainer writes it (`train/training_loop.py:265-285`: the
+    state dict without CLIP keys, `args.json` next to it) -> `sample.generate --model_path` (args.json overrides the
+    command line) -> results.npy, compared with the CPU oracle fed the same weights, conditioning and Philox noise."""
+    from gesturediffusion_amd.sample import generate
+    from gesturediffusion_amd.utils.init import init_state_dict
+    from oracle import mdm_forward as omf
+    from oracle import philox
+    from oracle import sampler as osamp
+    from oracle import schedule as osch
+    J, T, P, N, CH, SEED = 37, 20, 10, 3, 2, 7
+    cfg = dict(arch="mdm", njoints=J, nfeats=1, latent_dim=128, ff_size=1024, num_layers=2, num_heads=4, seed_poses=P)
+    sd = init_state_dict(cfg, seed=21, perturb=True)
+    run = tmp_path / "save" / "my_run"
+    run.mkdir(parents=True)
+    torch.save(sd, run / "model000012345.pt")
+    stored = dict(dataset="humanml", data_dir="", num_frames=T, arch="trans_enc", emb_trans_dec=False, layers=2,
+                  latent_dim=128, cond_mask_prob=0.1, lambda_rcxyz=0.0, lambda_vel=0.0, lambda_fc=0.0,
+                  unconstrained=False, use_text=False, use_audio=False, mfcc_input=True, use_wav_enc=False, seed_poses=P,
+                  noise_schedule="cosine", diffusion_steps=1000, sigma_small=True)
+    (run / "args.json").write_text(json.dumps(stored))
+    out = tmp_path / "out"
+    assert generate.main(["--model_path", str(run / "model000012345.pt"), "--synthetic", "--synthetic_njoints", str(J),
+                          "--layers", "8", "--latent_dim", "512", "--num_frames", "120", "--num_samples", str(N),
+                          "--chunks", str(CH), "--output_dir", str(out), "--seed", str(SEED), "--rng", "philox",
+                          "--timestep_respacing", "25", "--guidance_param", "2.5"]) == 0
+    got = np.load(out / "results.npy", allow_pickle=True).item()["motion"]       # written a moment ago by this test
+    assert got.shape == (N, J, 1, CH * T)                # layers / latent_dim / num_frames came from args.json
+    g = torch.Generator().manual_seed(SEED)
+    seed_all = torch.randn(N, J, 1, P, generator=g)
+    mfccs = [torch.randn(N, 26, 1, T, generator=g) for _ in range(CH)]
+    tab, tmap = osch.make_tables("cosine", 1000, [25])
+    tapes = [torch.stack([torch.from_numpy(philox.normal(N, J * T, SEED + 1000 * c, 0, k)).view(N, J, 1, T) for k in range(26)])
+             for c in range(CH)]
+    with torch.no_grad():
+        want = osamp.sample_chunks(lambda x, t, y: omf.cfg_forward(sd, cfg, x, t, y), tab, tmap, seed_all, mfccs, tapes, P,
+                                   scale=2.5)
+    assert rel_err(got, torch.cat(want, dim=3)) < LOOP_TOL
+
+
+# ------------------------------------------------------------------------------------------------ sharding
+def test_generate_two_ranks_equal_one_rank(tmp_path):
+    """The CLI on 2 ranks (both on this GPU, gloo for the end-of-chunk gather) must write the samples 1 rank writes:
+    sharded runs key their noise by the global sample index (an odd sample count makes the shards uneven)."""
+    from gesturediffusion_amd.sample import generate
+    base = ["--synthetic", "--latent_dim", "128", "--layers", "2", "--num_samples", "5", "--chunks", "2", "--num_frames",
+            "20", "--synthetic_njoints", "37", "--seed", "7", "--timestep_respacing", "25"]
+    one = tmp_path / "one"
+    assert generate.main(base + ["--rng", "philox", "--output_dir", str(one)]) == 0
+    two = tmp_path / "two"
+    env = dict(os.environ, GDX_SINGLE_GPU_RANKS="1", GDX_DIST_BACKEND="gloo", PYTHONPATH=REPO)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr",
+                        "127.0.0.1", "--master-port", "29541", "-m", "gesturediffusion_amd.sample.generate"] + base +
+                       ["--output_dir", str(two)], env=env, capture_output=True, text=True, timeout=600, cwd=REPO)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    a = np.load(one / "results.npy", allow_pickle=True).item()["motion"]         # both written by this test
+    b = np.load(two / "results.npy", allow_pickle=True).item()["motion"]
+    assert a.shape == b.shape == (5, 37, 1, 40) and np.array_equal(a, b)
+    with pytest.raises(ValueError):
+        generate.resolve_rng("torch", 2)

@@ -230,24 +230,37 @@ def test_shard_range_partitions():
 
 
 WORKER = r"""
-import os, sys, torch
+import os, sys, numpy as np, torch
 sys.path.insert(0, os.environ["GDX_REPO"])
 from gesturediffusion_amd.utils import dist_util
+from oracle import philox
 rank, world, device = dist_util.init_from_env(backend="gloo")
-total = 7
-lo, hi = dist_util.shard_range(total, rank, world)
-local = torch.arange(lo, hi, dtype=torch.float32).view(-1, 1, 1, 1).repeat(1, 3, 1, 4) + 100
-full = dist_util.gather_samples(local, total)
+J, T, SEED = 5, 6, 10
+# each rank fills ITS shard with the noise the sampler would draw: keyed by the GLOBAL sample index, so the gathered
+# batch must equal the batch one rank would have produced alone.  7 over 2 and 41 over 2 are uneven splits; 1 over 2
+# leaves rank 1 with an empty shard.
+for total in (7, 41, 8, 1):
+    lo, hi = dist_util.shard_range(total, rank, world)
+    local = torch.from_numpy(philox.normal(hi - lo, J * T, SEED, sample_offset=lo, step=3)).view(hi - lo, J, 1, T)
+    full = dist_util.gather_samples(local, total)
+    if rank == 0:
+        want = torch.from_numpy(philox.normal(total, J * T, SEED, sample_offset=0, step=3)).view(total, J, 1, T)
+        assert full.shape == want.shape and torch.equal(full, want), total
+    else:
+        assert full is None
+try:
+    dist_util.gather_samples(torch.zeros(3, J, 1, T), 41)          # wrong shard size is an error, not a hang
+    raise SystemExit("expected ValueError")
+except ValueError:
+    pass
 if rank == 0:
-    assert full.shape == (total, 3, 1, 4) and torch.equal(full[:, 0, 0, 0], torch.arange(total) + 100.0), full
     print("GATHER_OK")
-else:
-    assert full is None
 torch.distributed.barrier(); torch.distributed.destroy_process_group()
 """
 
 
 def test_world_size_2_shard_and_gather_gloo(tmp_path):
+    """Two ranks (gloo, CPU): shard_range + per-global-index fill + gather_samples == the unsharded batch."""
     script = tmp_path / "worker.py"
     script.write_text(WORKER)
     env = dict(os.environ, GDX_REPO=REPO, CUDA_VISIBLE_DEVICES="", HIP_VISIBLE_DEVICES="")

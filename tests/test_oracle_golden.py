@@ -1,10 +1,13 @@
 """Pins the CPU oracle against fixtures produced by the reference itself
 (oracle/tools/make_golden.py).  CPU only."""
+import os
+import sys
+
 import numpy as np
 import pytest
 import torch
 
-from conftest import load_golden, rel_err, weights_from
+from conftest import REPO, load_golden, rel_err, weights_from
 from oracle import mdm_forward as omf
 from oracle import sampler as osamp
 from oracle import schedule as osch
@@ -249,6 +252,22 @@ def test_ddim_reverse_tiny(arch):
             t = torch.tensor([ti] * x.shape[0])
             x = osamp.ddim_reverse_step(tab, omf.forward(p, cfg, x, mapt[t], y), x, t)
     assert rel_err(x, g["ddim10_reverse3"]) < 2e-5
+
+
+@pytest.mark.parametrize("arch", ["mdm", "mdm_old"])
+def test_chunk_driver_vs_reference_golden(arch):
+    """three chunks chained through `sample_out[..., -seed_poses:]` with guidance 2.5 -- the oracle's driver
+    against the reference's own p_sample_loop + ClassifierFreeSampleModel driven the same way (chunks_tiny.npz)."""
+    sys.path.insert(0, os.path.join(REPO, "oracle", "tools"))
+    from make_golden import CHUNKS, TINY as GT, chunk_inputs
+    g = load_golden("chunks_tiny.npz")
+    cfg, sd, seedp, mfccs, tapes = chunk_inputs(dict(GT, arch=arch, njoints=CHUNKS["njoints"]))
+    tab, tmap = osch.make_tables("cosine", 1000, CHUNKS["respacing"])
+    with torch.no_grad():
+        outs = osamp.sample_chunks(lambda x, t, y: omf.cfg_forward(sd, cfg, x, t, y), tab, tmap, seedp, mfccs, tapes,
+                                   cfg["seed_poses"], scale=CHUNKS["scale"])
+    for c, o in enumerate(outs):
+        assert rel_err(o, g[f"{arch}.chunk{c}"]) < 5e-5, c
 
 
 def test_sampler_update_bit_exact():
