@@ -520,14 +520,17 @@ static int gemm(int am, int bm, int om, int ep, const GemmParams& p, hipStream_t
 
 // The per-step kernel sequence.  temb: [*, d] rows (row stride tstride, 0 = shared by the batch).
 // Writes x0 for Beff samples into x0_out ([Beff, J, T]).
-static int forward_core_f16(gdx_model* h, const float* x, const float* temb, int tstride, int mode, float* x0_out,
-                            hipStream_t s, const int* state);
+static int forward_core_f16(gdx_model* h, const float* x, const float* temb, int tstride, const float* c2t, int mode,
+                            float* x0_out, hipStream_t s, const int* state);
 
-// state != nullptr (graph replay, gdx_sample_loop): temb is the BASE of the loop's timestep-embedding table and the
-// row index is read from device memory (state[0]) by the conditioning-token kernel.
-static int forward_core(gdx_model* h, const float* x, const float* temb, int tstride, int mode, float* x0_out,
-                        hipStream_t s, const int* state = nullptr) {
-    if (h->f16) return forward_core_f16(h, x, temb, tstride, mode, x0_out, s, state);
+// c2t (V2 only): W_coa * temb rows with the same row stride as temb -- the timestep half of the coarse slice of
+// project_to_lat (model/mdm.py:154-169), computed by the caller with the row-independent small_linear kernel: per
+// sample in gdx_forward, once per kept step in gdx_sample_loop, hence the same bits on both sides of the seam.
+// state != nullptr (graph replay, gdx_sample_loop): temb / c2t are the BASES of the loop's tables and the row index is
+// read from device memory (state[0]) by the conditioning-token kernel.
+static int forward_core(gdx_model* h, const float* x, const float* temb, int tstride, const float* c2t, int mode,
+                        float* x0_out, hipStream_t s, const int* state = nullptr) {
+    if (h->f16) return forward_core_f16(h, x, temb, tstride, c2t, mode, x0_out, s, state);
     const int B = h->B, T = h->T, S = h->S, d = h->d, J = h->J;
     const int Beff = mode == GDX_CFG ? 2 * B : B;
     const float* seed_emb = mode == GDX_UNCOND ? h->seed_cat + (size_t)B * d : h->seed_cat;
@@ -537,21 +540,17 @@ static int forward_core(gdx_model* h, const float* x, const float* temb, int tst
     const int Jp = h->in_x.kpad;
     HIPCHK(launch_transpose_in(x, h->xt, Beff, B, J, T, Jp, s));
     if (h->cfg.arch == GDX_ARCH_MDM_OLD) {
-        HIPCHK(launch_token0(temb, tstride, seed_emb, h->pe, h->xa, nullptr, nullptr, nullptr, nullptr, nullptr, state, Beff, B, S, d, s));
+        HIPCHK(launch_token0(temb, tstride, seed_emb, h->pe, h->xa, nullptr, nullptr, nullptr, nullptr, state, Beff, B, S, d, s));
         // frames -> rows (b, t+1) of the encoder input, + hoisted MFCC/bias/PE term      (model/mdm_old.py:104-112)
         p = GemmParams{h->xt, Jp, h->in_x.w, h->in_x.kpad, nullptr, h->addend, d, nullptr, 0, h->xa, d, Beff * T, d, Jp, T, B};
         if (gemm(A_ROWS, B_WEIGHT, OUT_TOKROWS, EPI_RES, p, s)) return -1;
     } else {
-        // inside a sampling loop the coarse slice of project_to_lat is table row + per-sample vector (see gdx_sample_loop)
-        const bool hoist = h->c2t_valid && tstride == 0 && temb >= h->temb_table &&
-                           temb < h->temb_table + (size_t)h->temb_table_rows * d;
-        const float* c2t_row = hoist ? h->c2t_table + (temb - h->temb_table) : nullptr;
+        // coarse slice of project_to_lat = W_coa temb (c2t, from the caller) + W_coa seed_emb (c2_seed, per conditioning)
+        if (!c2t) return fail("forward_core: V2 needs the W_coa * temb rows");
         const float* c2s = mode == GDX_UNCOND ? h->c2_seed + (size_t)B * d : h->c2_seed;
-        HIPCHK(launch_token0(temb, tstride, seed_emb, nullptr, h->xa, nullptr, h->coa, c2t_row, c2s, hoist ? h->c2 : nullptr,
-                             state, Beff, B, S, d, s));
+        HIPCHK(launch_token0(temb, tstride, seed_emb, nullptr, h->xa, nullptr, c2t, c2s, h->c2, state, Beff, B, S, d, s));
         p = GemmParams{h->xt, Jp, h->in_x.w, h->in_x.kpad, h->in_x.bias, nullptr, 0, nullptr, 0, h->emb_pose, d, Beff * T, d, Jp, T, B};
         if (gemm(A_ROWS, B_WEIGHT, OUT_ROWS, EPI_BIAS, p, s)) return -1;
-        if (!hoist) HIPCHK(launch_small_linear(h->coa, d, h->proj_coa.w, h->proj_coa.kpad, nullptr, h->c2, d, Beff, d, d, 0, s));
         p = GemmParams{h->emb_pose, d, h->proj_pose.w, h->proj_pose.kpad, nullptr, h->addend, d, h->c2, d, h->xseq, d, Beff * T, d, d, T, B};
         if (gemm(A_ROWS, B_WEIGHT, OUT_ROWS, EPI_RES_VEC, p, s)) return -1;
         HIPCHK(launch_local_attention(h->xseq, h->rope_cos, h->rope_sin, h->xa, nullptr, Beff, T, d, h->cfg.cl_head,
@@ -619,8 +618,8 @@ static int gemm_f16(const _Float16* A, int lda, const Packed& P, const float* bi
 // residual stream xa16 / xb16, LayerNorm inputs and outputs, q/k/v, probabilities, context) is fp16; every
 // accumulation (MFMA, bias / residual terms in the GEMM epilogues, LayerNorm statistics, softmax) is fp32.  The two
 // boundary tensors stay fp32: the pose tensor read by the input transpose and the x0 prediction (fp32 output GEMM).
-static int forward_core_f16(gdx_model* h, const float* x, const float* temb, int tstride, int mode, float* x0_out,
-                            hipStream_t s, const int* state) {
+static int forward_core_f16(gdx_model* h, const float* x, const float* temb, int tstride, const float* c2t, int mode,
+                            float* x0_out, hipStream_t s, const int* state) {
     const int B = h->B, T = h->T, S = h->S, d = h->d, J = h->J;
     const int Beff = mode == GDX_CFG ? 2 * B : B;
     const float* seed_emb = mode == GDX_UNCOND ? h->seed_cat + (size_t)B * d : h->seed_cat;
@@ -629,20 +628,15 @@ static int forward_core_f16(gdx_model* h, const float* x, const float* temb, int
     float* const tap32 = h->keep_taps ? h->xa : nullptr;              // fp32 copies only for the parity taps
     HIPCHK(launch_transpose_in_f16(x, h->xt16, Beff, B, J, T, Jp, s));
     if (h->cfg.arch == GDX_ARCH_MDM_OLD) {
-        HIPCHK(launch_token0(temb, tstride, seed_emb, h->pe, h->xa, h->xa16, nullptr, nullptr, nullptr, nullptr, state, Beff, B, S, d, s));
+        HIPCHK(launch_token0(temb, tstride, seed_emb, h->pe, h->xa, h->xa16, nullptr, nullptr, nullptr, state, Beff, B, S, d, s));
         if (gemm_f16(h->xt16, Jp, h->in_x, nullptr, h->addend, d, nullptr, 0, tap32, d, h->xa16, d, Beff * T, d, T, 1, 0, s))
             return -1;
     } else {
-        // inside a sampling loop the coarse slice of project_to_lat is table row + per-sample vector (see gdx_sample_loop)
-        const bool hoist = h->c2t_valid && tstride == 0 && temb >= h->temb_table &&
-                           temb < h->temb_table + (size_t)h->temb_table_rows * d;
-        const float* c2t_row = hoist ? h->c2t_table + (temb - h->temb_table) : nullptr;
+        if (!c2t) return fail("forward_core: V2 needs the W_coa * temb rows");
         const float* c2s = mode == GDX_UNCOND ? h->c2_seed + (size_t)B * d : h->c2_seed;
-        HIPCHK(launch_token0(temb, tstride, seed_emb, nullptr, h->xa, h->xa16, h->coa, c2t_row, c2s, hoist ? h->c2 : nullptr,
-                             state, Beff, B, S, d, s));
+        HIPCHK(launch_token0(temb, tstride, seed_emb, nullptr, h->xa, h->xa16, c2t, c2s, h->c2, state, Beff, B, S, d, s));
         if (gemm_f16(h->xt16, Jp, h->in_x, h->in_x.bias, nullptr, 0, nullptr, 0, nullptr, 0, h->emb16, d, Beff * T, d, T, 0, 0, s))
             return -1;
-        if (!hoist) HIPCHK(launch_small_linear(h->coa, d, h->proj_coa.w, h->proj_coa.kpad, nullptr, h->c2, d, Beff, d, d, 0, s));
         if (local_attention_f16_supported(d, h->cfg.cl_head, h->cfg.window)) {
             if (gemm_f16(h->emb16, d, h->proj_pose, nullptr, h->addend, d, h->c2, d, nullptr, 0, h->xseq16, d, Beff * T, d, T, 0, 0, s))
                 return -1;
@@ -693,17 +687,13 @@ static int check_ready(gdx_model* h, const char* who) {
     return 0;
 }
 
-// timestep embedding rows for idx[M] (model/mdm.py:296-310): pe gather -> Linear -> SiLU -> Linear
-static int time_embed(gdx_model* h, const int64_t* idx, int M, float* gathered, float* hidden, float* out,
-                      bool table, hipStream_t s) {
+// timestep embedding rows for idx[M] (model/mdm.py:296-310): pe gather -> Linear -> SiLU -> Linear.  The same
+// row-independent kernel serves the per-sample rows of gdx_forward and the whole-loop table of gdx_sample_loop, so a
+// timestep's embedding has the same bits on both sides of the seam (fused loop == step-wise protocol, bit for bit).
+static int time_embed(gdx_model* h, const int64_t* idx, int M, float* gathered, float* hidden, float* out, hipStream_t s) {
     const int d = h->d;
     HIPCHK(launch_gather_rows(h->pe, idx, gathered, M, d, h->pe_rows, s));
     HIPCHK(launch_small_linear(gathered, d, h->time0.w, h->time0.kpad, h->time0.bias, hidden, d, M, d, d, 1, s));
-    if (table && M >= 64) {   // whole-loop tables only (per-sample embeddings keep one batch-size-independent kernel):
-                              // the persistent GEMM; the caller pads `hidden` / `out` by >= GDX_ROW_PAD rows
-        GemmParams p{hidden, d, h->time2.w, h->time2.kpad, h->time2.bias, nullptr, 0, nullptr, 0, out, d, M, d, d, 1, 1};
-        return gemm(A_ROWS, B_WEIGHT, OUT_ROWS, EPI_BIAS, p, s);
-    }
     HIPCHK(launch_small_linear(hidden, d, h->time2.w, h->time2.kpad, h->time2.bias, out, d, M, d, d, 0, s));
     return 0;
 }
@@ -715,9 +705,14 @@ extern "C" int gdx_forward(gdx_handle_t h, const float* x, const int64_t* timest
     if (mode < GDX_COND || mode > GDX_CFG) return fail("gdx_forward: bad mode");
     if (mode == GDX_CFG && !scale) return fail("gdx_forward: GDX_CFG needs scale");
     hipStream_t s = (hipStream_t)stream;
-    if (time_embed(h, timesteps, h->B, h->temb_in, h->temb_h, h->temb, false, s)) return -1;
-    if (mode != GDX_CFG) return forward_core(h, x, h->temb, h->d, mode, out, s);
-    if (forward_core(h, x, h->temb, h->d, mode, h->x0, s)) return -1;
+    if (time_embed(h, timesteps, h->B, h->temb_in, h->temb_h, h->temb, s)) return -1;
+    const float* c2t = nullptr;
+    if (h->cfg.arch == GDX_ARCH_MDM) {       // W_coa * temb per sample (h->coa doubles as the [B, d] buffer for it)
+        HIPCHK(launch_small_linear(h->temb, h->d, h->proj_coa.w, h->proj_coa.kpad, nullptr, h->coa, h->d, h->B, h->d, h->d, 0, s));
+        c2t = h->coa;
+    }
+    if (mode != GDX_CFG) return forward_core(h, x, h->temb, h->d, c2t, mode, out, s);
+    if (forward_core(h, x, h->temb, h->d, c2t, mode, h->x0, s)) return -1;
     const int64_t per = (int64_t)h->J * h->T;
     HIPCHK(launch_cfg_blend(h->x0, h->x0 + (size_t)h->B * per, scale, out, h->B, per, s));
     return 0;
@@ -759,15 +754,11 @@ extern "C" int gdx_sample_loop(gdx_handle_t h, const gdx_loop_args_t* a, void* s
     HIPCHK(hipMemcpyAsync(h->tmap_dev, h->tmap_host.data(), sizeof(int64_t) * a->num_steps, hipMemcpyHostToDevice, s));
     float* scratch0 = table + (size_t)h->temb_table_rows * d;
     float* scratch1 = scratch0 + (size_t)h->temb_table_rows * d;
-    if (time_embed(h, h->tmap_dev, a->num_steps, scratch0, scratch1, table, true, s)) return -1;
+    if (time_embed(h, h->tmap_dev, a->num_steps, scratch0, scratch1, table, s)) return -1;
     if (h->cfg.arch == GDX_ARCH_MDM) {
-        // timestep half of the coarse slice of project_to_lat for every kept step, once per loop
-        if (a->num_steps >= 64) {
-            GemmParams p{table, d, h->proj_coa.w, h->proj_coa.kpad, nullptr, nullptr, 0, nullptr, 0, h->c2t_table, d, a->num_steps, d, d, 1, 1};
-            if (gemm(A_ROWS, B_WEIGHT, OUT_ROWS, EPI_BIAS, p, s)) return -1;
-        } else {
-            HIPCHK(launch_small_linear(table, d, h->proj_coa.w, h->proj_coa.kpad, nullptr, h->c2t_table, d, a->num_steps, d, d, 0, s));
-        }
+        // timestep half of the coarse slice of project_to_lat for every kept step, once per loop (same kernel as
+        // gdx_forward's per-sample rows)
+        HIPCHK(launch_small_linear(table, d, h->proj_coa.w, h->proj_coa.kpad, nullptr, h->c2t_table, d, a->num_steps, d, d, 0, s));
         h->c2t_valid = true;
     }
     h->tables_valid = true;
@@ -790,7 +781,8 @@ extern "C" int gdx_sample_loop(gdx_handle_t h, const gdx_loop_args_t* a, void* s
         u.out = a->x; u.pred_xstart = nullptr;
     };
     auto eager_step = [&](int idx, int k) -> int {
-        if (forward_core(h, a->x, table + (size_t)idx * d, 0, a->mode, h->x0, s)) return -1;
+        if (forward_core(h, a->x, table + (size_t)idx * d, 0, h->c2t_table ? h->c2t_table + (size_t)idx * d : nullptr, a->mode, h->x0, s))
+            return -1;
         gdx_update_args_t u;
         fill_update(u, idx, k);
         if (gdx_sampler_update(&u, stream)) return -1;
@@ -833,7 +825,7 @@ extern "C" int gdx_sample_loop(gdx_handle_t h, const gdx_loop_args_t* a, void* s
                  hipStreamWaitEvent(h->gstream, h->gev_in, 0) == hipSuccess;
         }
         if (ok && hipStreamBeginCapture(h->gstream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
-            int rc = forward_core(h, a->x, table, 0, a->mode, h->x0, h->gstream, h->gstate);
+            int rc = forward_core(h, a->x, table, 0, h->c2t_table, a->mode, h->x0, h->gstream, h->gstate);
             if (!rc) {
                 gdx_update_args_t u;
                 fill_update(u, 0, 0);

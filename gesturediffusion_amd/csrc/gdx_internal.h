@@ -99,12 +99,12 @@ hipError_t launch_gather_rows(const float* table, const int64_t* idx, float* out
 // out[(b*rps + t + off)*d + n] = sum_c mfcc[((b%Bmod)*C + c)*T + t] * W[n*ldw + c] + bias[n] (+ pe[(t+1)*d + n] if pe)
 hipError_t launch_mfcc_project(const float* mfcc, const float* W, int ldw, const float* bias, const float* pe,
                                float* out, int B, int Bmod, int C, int T, int d, int rps, int off, hipStream_t s);
-// token 0 of the encoder input: enc[b*S*d + n] = temb[(b%Bmod)*tstride + n] + seed[b*d + n] (+ pe0[n]);
-// also writes coa[b*d+n] (same value without pe0) when coa != nullptr.
-// c2 != nullptr: c2[b*d+n] = c2t_row[n] + c2_seed[b*d+n]  (V2: the coarse slice of project_to_lat, hoisted per loop /
-// per conditioning instead of a [B,d] x [d,d] linear per step)
+// token 0 of the encoder input: enc[b*S*d + n] = temb[(b%Bmod)*tstride + n] + seed[b*d + n] (+ pe0[n]).
+// c2 != nullptr (V2): c2[b*d+n] = c2t[(b%Bmod)*tstride + n] + c2_seed[b*d+n] -- the coarse slice of project_to_lat applied to
+// (temb + seed_emb), split into its timestep half (c2t = W_coa temb rows, same stride as temb) and its seed half
+// (per conditioning) instead of a [B,d] x [d,d] linear per step
 hipError_t launch_token0(const float* temb, int tstride, const float* seed_emb, const float* pe0,
-                         float* enc, _Float16* enc16, float* coa, const float* c2t_row, const float* c2_seed, float* c2,
+                         float* enc, _Float16* enc16, const float* c2t, const float* c2_seed, float* c2,
                          const int* state, int B, int Bmod, int S, int d, hipStream_t s);
 // graph replay of the sampling loop: device-resident {schedule index, executed-step number} (sampler.hip)
 hipError_t launch_set_state(int* st, int idx, int k, hipStream_t s);

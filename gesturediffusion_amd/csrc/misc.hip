@@ -366,29 +366,28 @@ hipError_t launch_mfcc_project(const float* mfcc, const float* W, int ldw, const
 // conditioning token (model/mdm_old.py:94-111: emb_t + emb_seed, then + pe[0]; model/mdm.py:154-160,197)
 __global__ void token0_kernel(const float* __restrict__ temb, int tstride, const float* __restrict__ seed_emb,
                               const float* __restrict__ pe0, float* __restrict__ enc, _Float16* __restrict__ enc16,
-                              float* __restrict__ coa, const float* __restrict__ c2t_row,
-                              const float* __restrict__ c2_seed, float* __restrict__ c2, const int* __restrict__ state,
-                              int B, int Bmod, int S, int d) {
+                              const float* __restrict__ c2t, const float* __restrict__ c2_seed, float* __restrict__ c2,
+                              const int* __restrict__ state, int B, int Bmod, int S, int d) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= B * d) return;
     const int b = i / d, n = i % d;
-    if (state) {                            // graph replay: temb / c2t_row are table bases, the row comes from device memory
+    if (state) {                            // graph replay: temb / c2t are table bases, the row comes from device memory
         temb += (long)state[0] * d;
-        if (c2t_row) c2t_row += (long)state[0] * d;
+        if (c2t) c2t += (long)state[0] * d;
     }
-    float v = temb[(long)(b % Bmod) * tstride + n] + seed_emb[i];
-    if (coa) coa[i] = v;
-    if (c2) c2[i] = c2t_row[n] + c2_seed[i];      // hoisted coarse slice of project_to_lat: W_coa temb + W_coa seed_emb
+    const long trow = (long)(b % Bmod) * tstride + n;
+    float v = temb[trow] + seed_emb[i];
+    if (c2) c2[i] = c2t[trow] + c2_seed[i];       // coarse slice of project_to_lat: W_coa temb + W_coa seed_emb
     if (pe0) v += pe0[n];
     enc[(long)b * S * d + n] = v;
     if (enc16) enc16[(long)b * S * d + n] = (_Float16)v;
 }
 
 hipError_t launch_token0(const float* temb, int tstride, const float* seed_emb, const float* pe0, float* enc,
-                         _Float16* enc16, float* coa, const float* c2t_row, const float* c2_seed, float* c2,
-                         const int* state, int B, int Bmod, int S, int d, hipStream_t s) {
+                         _Float16* enc16, const float* c2t, const float* c2_seed, float* c2, const int* state, int B,
+                         int Bmod, int S, int d, hipStream_t s) {
     hipLaunchKernelGGL(token0_kernel, dim3((B * d + 255) / 256), dim3(256), 0, s, temb, tstride, seed_emb, pe0, enc,
-                       enc16, coa, c2t_row, c2_seed, c2, state, B, Bmod, S, d);
+                       enc16, c2t, c2_seed, c2, state, B, Bmod, S, d);
     return hipGetLastError();
 }
 

@@ -72,6 +72,11 @@ def gather_samples(local, total, dst=0):
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return local
     world, rank = dist.get_world_size(), dist.get_rank()
+    if local.is_cuda and dist.get_backend() != "nccl":
+        # rehearsal backends (gloo) move host memory and know nothing about HIP streams: stage through the host
+        # (.cpu() waits for the sampling loop that is still in flight on the current stream)
+        full = gather_samples(local.cpu(), total, dst)
+        return full.to(local.device) if full is not None else None
     spans = [shard_range(total, r, world) for r in range(world)]
     lo, hi = spans[rank]
     if local.shape[0] != hi - lo:

@@ -231,7 +231,9 @@ def test_checkpoint_roundtrip_vs_oracle(tmp_path):
     sd = init_state_dict(cfg, seed=21, perturb=True)
     run = tmp_path / "save" / "my_run"
     run.mkdir(parents=True)
-    torch.save(sd, run / "model000012345.pt")
+    # what the trainer saves: the module's state_dict (parameters AND buffers) minus clip_model.* keys
+    trained = build_model("mdm", cfg, sd).cpu()
+    torch.save({k: v for k, v in trained.state_dict().items() if not k.startswith("clip_model.")}, run / "model000012345.pt")
     stored = dict(dataset="humanml", data_dir="", num_frames=T, arch="trans_enc", emb_trans_dec=False, layers=2,
                   latent_dim=128, cond_mask_prob=0.1, lambda_rcxyz=0.0, lambda_vel=0.0, lambda_fc=0.0,
                   unconstrained=False, use_text=False, use_audio=False, mfcc_input=True, use_wav_enc=False, seed_poses=P,
