@@ -1,0 +1,98 @@
+// Micro-benchmark (measurement only): the L2 -> LDS staging rate of the fp16 GEMM's operand stream as a function of the
+// bytes each LDS-DMA piece takes from one row.  The 256 x 256 fp16 tile stages 32 KiB per 32-deep K step; with 64-byte
+// row chunks (K slab = 32 halves) a 1 KiB piece touches 16 different 128-byte lines and uses half of each.
+//   mode 0: 16 rows x  64 B per piece, K slab 32 (gemmh8_kernel as of round 1)
+//   mode 1:  8 rows x 128 B per piece, K slab 64 (whole lines)
+//   mode 2: 16 rows x  64 B, but the two halves of a line are fetched by CONSECUTIVE pieces (slab pair g, g+1)
+// Same tile walk as the kernel (XCD-aware, tile = lid + t*G over 261 x 4 tiles of M = 66 688, N = 1 024, K = 1 024),
+// 4-stage ring, counted vmcnt + barrier per step, no MFMA.
+// build: hipcc -O3 --offload-arch=gfx950 dma_probe.hip -o dma_probe ; run: ./dma_probe
+#include <hip/hip_runtime.h>
+#include <cstdio>
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+template <int N>
+__device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+template <int MODE>
+__global__ __launch_bounds__(512, 1) void probe(const _Float16* A, const _Float16* W, int M, int N, int K, int ntn, int ntiles,
+                                                float* sink) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid) >> 6, lane = tid & 63;
+    const int G = gridDim.x;
+    int lid;
+    {
+        const int bid = blockIdx.x, q = G >> 3, r = G & 7, xcd = bid & 7, idx = bid >> 3;
+        lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int my_tiles = lid < ntiles ? (ntiles - lid + G - 1) / G : 0;
+    const auto rsrcA = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(A), (short)0, M * K * 2, 0x00020000);
+    const auto rsrcW = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(W), (short)0, N * K * 2, 0x00020000);
+    // a step stages 32 pieces: 16 of A (256 rows x 64 B, or 128 rows x 128 B) and 16 of W; wave w issues w, w+8, w+16, w+24
+    int voff[4];
+    for (int i = 0; i < 4; ++i) {
+        const int piece = (wave + 8 * i) & 15;
+        const int row = MODE == 1 ? piece * 8 + (lane >> 3) : piece * 16 + (lane >> 2);
+        const int col = MODE == 1 ? (lane & 7) * 16 : (lane & 3) * 16;
+        voff[i] = row * K * 2 + col;
+    }
+    const int nk = K / 32;                                        // 32 KiB per step in every mode
+    int stage = 0;
+    for (int t = 0; t < my_tiles; ++t) {
+        const int tile = lid + t * G;
+        const int a_base = (tile / ntn) * 256 * K * 2, w_base = (tile % ntn) * 256 * K * 2;
+        for (int ks = 0; ks < nk; ++ks) {
+            char* sb = smem + stage * 32768;
+            // mode 1 alternates the row halves of the tile between steps (128 rows x 128 B per operand per step)
+            const int half_rows = MODE == 1 ? (ks & 1) * 128 * K * 2 : 0;
+            const int kof = MODE == 1 ? (ks >> 1) * 128 : ks * 64;   // mode 1: a pair of steps covers one 128-B column
+            for (int i = 0; i < 4; ++i) {
+                const int piece = wave + 8 * i;
+                const bool isA = piece < 16;
+                const int so = (isA ? a_base : w_base) + half_rows + kof;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(isA ? rsrcA : rsrcW, (lds_ptr_t)(sb + piece * 1024), 16, voff[i], so, 0, 0);
+                if (MODE == 2) {                                  // the other half of the same lines, straight away
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(isA ? rsrcA : rsrcW, (lds_ptr_t)(smem + ((stage + 1) & 3) * 32768 + piece * 1024),
+                                                             16, voff[i], so + 64, 0, 0);
+                }
+            }
+            if (MODE == 2) { ++ks; wait_vm<8>(); } else { wait_vm<4>(); }
+            __builtin_amdgcn_s_barrier();
+            stage = (stage + (MODE == 2 ? 2 : 1)) & 3;
+        }
+    }
+    wait_vm<0>();
+    __builtin_amdgcn_s_barrier();
+    if (sink && tid == 0) sink[blockIdx.x] = reinterpret_cast<float*>(smem)[lane];
+#endif
+}
+
+template <int MODE>
+static void run(const char* name, const _Float16* A, const _Float16* W, float* sink) {
+    const int M = 66688, N = 1024, K = 1024, ntn = N / 256, ntiles = ((M + 255) / 256) * ntn;
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&probe<MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    hipLaunchKernelGGL((probe<MODE>), dim3(256), dim3(512), 131072, 0, A, W, M, N, K, ntn, ntiles, sink);
+    hipEventRecord(e0, 0);
+    const int reps = 5;
+    for (int r = 0; r < reps; ++r) hipLaunchKernelGGL((probe<MODE>), dim3(256), dim3(512), 131072, 0, A, W, M, N, K, ntn, ntiles, sink);
+    hipEventRecord(e1, 0); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    const double us = ms * 1e3 / reps;
+    const double bytes = (double)ntiles * (K / 32) * 32768.0;       // same bytes in every mode
+    printf("%-46s %8.1f us per launch  %.2f TB/s chip-wide  %.1f GB/s per CU  (%s)\n", name, us, bytes / us / 1e6, bytes / us / 1e3 / 256,
+           hipGetErrorString(hipGetLastError()));
+}
+
+int main() {
+    const size_t an = (size_t)(66688 + 256) * 1024, wn = (size_t)1024 * 1024;
+    _Float16 *A, *W; float* sink;
+    hipMalloc(&A, an * 2); hipMalloc(&W, wn * 2); hipMalloc(&sink, 4096);
+    hipMemset(A, 0x3c, an * 2); hipMemset(W, 0x3c, wn * 2);
+    run<0>("64 B per row per piece (K slab 32)", A, W, sink);
+    run<1>("128 B per row per piece (K slab 64)", A, W, sink);
+    run<2>("64 B halves of a line back to back (slab pair)", A, W, sink);
+    run<0>("64 B per row per piece (K slab 32), again", A, W, sink);
+    return 0;
+}
