@@ -42,7 +42,7 @@ class UpdateArgs(C.Structure):
         ("inpaint_mask", C.c_void_p), ("inpaint_motion", C.c_void_p), ("noise", C.c_void_p),
         ("const_noise", C.c_int32), ("philox_seed", C.c_uint64), ("sample_offset", C.c_uint64),
         ("rng_step", C.c_uint32), ("out", C.c_void_p), ("pred_xstart", C.c_void_p),
-        ("cond_grad", C.c_void_p), ("cond_coef", C.c_void_p),
+        ("cond_grad", C.c_void_p), ("cond_coef", C.c_void_p), ("clip_denoised", C.c_int32),
     ]
 
 
@@ -61,7 +61,7 @@ class LoopArgs(C.Structure):
         ("inpaint_mask", C.c_void_p), ("inpaint_motion", C.c_void_p), ("noise_tape", C.c_void_p),
         ("const_noise", C.c_int32), ("philox_seed", C.c_uint64), ("sample_offset", C.c_uint64),
         ("dump", C.c_void_p), ("dump_steps", C.c_void_p), ("n_dump", C.c_int32),
-        ("run_steps", C.c_int32), ("k_base", C.c_int32),
+        ("run_steps", C.c_int32), ("k_base", C.c_int32), ("clip_denoised", C.c_int32),
     ]
 
 

@@ -779,6 +779,7 @@ extern "C" int gdx_sample_loop(gdx_handle_t h, const gdx_loop_args_t* a, void* s
         u.const_noise = a->const_noise;
         u.philox_seed = a->philox_seed; u.sample_offset = a->sample_offset; u.rng_step = (uint32_t)(k + 1);
         u.out = a->x; u.pred_xstart = nullptr;
+        u.clip_denoised = a->clip_denoised;
     };
     auto eager_step = [&](int idx, int k) -> int {
         if (forward_core(h, a->x, table + (size_t)idx * d, 0, h->c2t_table ? h->c2t_table + (size_t)idx * d : nullptr, a->mode, h->x0, s))

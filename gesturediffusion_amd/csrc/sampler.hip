@@ -73,6 +73,7 @@ struct UpdateDev {
     // cond_fn guidance (reference :418-494): gradient tensor and, for DDIM, the per-step sqrt(1 - alpha_bar) table
     const float* grad;
     const float* gcoef;
+    int clip;               // clip_denoised: x0 clamped to [-1, 1] after the CFG / inpainting blends (reference :349-355)
 };
 
 template <bool VEC>
@@ -107,6 +108,10 @@ __global__ __launch_bounds__(256) void update_kernel(const UpdateDev a) {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
             if (i < nval && a.mask[e0 + i]) x0[i] = a.motion[e0 + i];
+    }
+    if (a.clip) {                                 // torch.clamp semantics: a NaN stays a NaN
+#pragma unroll
+        for (int i = 0; i < 4; ++i) x0[i] = x0[i] < -1.0f ? -1.0f : (x0[i] > 1.0f ? 1.0f : x0[i]);
     }
     if (noise) {
         const long z0 = a.const_noise ? 4L * grp : e0;
@@ -324,6 +329,7 @@ static int sampler_update_impl(const gdx_update_args_t* a, const int* state, lon
     d.rng_step = a->rng_step; d.out = a->out; d.pred = a->pred_xstart;
     d.state = state; d.noise_stride = noise_stride;
     d.grad = a->cond_grad; d.gcoef = a->cond_coef;
+    d.clip = a->clip_denoised;
     if (d.grad && a->kind != GDX_SAMPLER_P && !d.gcoef) return gdx_set_error_("gdx_sampler_update: cond_grad needs cond_coef for DDIM");
     const long total = d.groups * d.batch;
     if (total == 0) return 0;

@@ -218,22 +218,24 @@ class GaussianDiffusion:
             mask, motion = y["inpainting_mask"], y["inpainted_motion"]
             assert model_output.shape == mask.shape == motion.shape
         x0 = E.f32c(model_output, "model output")
-        if denoised_fn is not None or clip_denoised:
-            # rare path (every reference caller passes clip_denoised=False, denoised_fn=None)
+        xc = E.f32c(x, "x")
+        tt = t.to(th.int64).contiguous()
+        if denoised_fn is not None:
+            # rare path (every reference caller passes denoised_fn=None): the reference applies the inpainting blend, then
+            # denoised_fn, then the clamp (:307-311, :349-355).  The blend runs in the update kernel (its pred_xstart output,
+            # zero noise weight irrelevant), the user's callable on the result, the clamp in the update proper.
             if mask is not None:
-                x0 = (x0 * ~mask) + (motion * mask)
-                mask = motion = None
-            if denoised_fn is not None:
-                x0 = denoised_fn(x0)
-            if clip_denoised:
-                x0 = x0.clamp(-1, 1)
-            x0 = x0.contiguous()
+                blended = th.empty_like(xc)
+                E.sampler_update(kind, self.coef_table(kind, x.device, eta), xc, x0, th.empty_like(xc), t=tt,
+                                 inpaint_mask=mask.contiguous(), inpaint_motion=E.f32c(motion, "inpainted_motion"),
+                                 noise=th.zeros_like(xc), pred_xstart=blended)
+                x0, mask, motion = blended, None, None
+            x0 = E.f32c(denoised_fn(x0), "denoised_fn output")
         assert x0.shape == x.shape
         if noise is None:
             noise = th.randn_like(x)                                      # drawn even at t == 0 / eta == 0
         if const_noise:
             noise = noise[[0]].contiguous()
-        xc = E.f32c(x, "x")
         out = th.empty_like(xc)
         pred = th.empty_like(xc)
         grad = gcoef = None
@@ -245,11 +247,11 @@ class GaussianDiffusion:
             grad = E.f32c(self._call_cond_fn(cond_fn, x, t, model_kwargs), "cond_fn gradient")
             assert grad.shape == x.shape
             gcoef = self._cond_coef(x.device) if kind == GDX_SAMPLER_DDIM else None
-        E.sampler_update(kind, self.coef_table(kind, x.device, eta), xc, x0, out, t=t.to(th.int64).contiguous(),
+        E.sampler_update(kind, self.coef_table(kind, x.device, eta), xc, x0, out, t=tt,
                          inpaint_mask=mask.contiguous() if mask is not None else None,
                          inpaint_motion=E.f32c(motion, "inpainted_motion") if motion is not None else None,
                          noise=E.f32c(noise, "noise"), const_noise=const_noise, pred_xstart=pred, cond_grad=grad,
-                         cond_coef=gcoef)
+                         cond_coef=gcoef, clip_denoised=clip_denoised)
         return {"sample": out, "pred_xstart": pred}
 
     def p_sample(self, model, x, t, clip_denoised=True, denoised_fn=None, cond_fn=None, model_kwargs=None,
@@ -311,10 +313,10 @@ class GaussianDiffusion:
             raise ValueError(f"rng must be 'torch' or 'philox', got {rng!r}")
         device, img, indices = self._prepare_loop(model, shape, noise, device, skip_timesteps, init_image, rng,
                                                   philox_seed, sample_offset, noise_tape)
-        fused = not every_step and _is_native(model) and not clip_denoised and denoised_fn is None and cond_fn is None
+        fused = not every_step and _is_native(model) and denoised_fn is None and cond_fn is None
         if fused:
             yield from self._fused_loop(kind, model, img, indices, model_kwargs, eta, const_noise, rng, philox_seed,
-                                        sample_offset, noise_tape, dump_steps, progress)
+                                        sample_offset, noise_tape, dump_steps, progress, clip_denoised)
             return
         if progress:
             from tqdm.auto import tqdm
@@ -333,7 +335,7 @@ class GaussianDiffusion:
             img = out["sample"]
 
     def _fused_loop(self, kind, model, img, indices, model_kwargs, eta, const_noise, rng, philox_seed, sample_offset,
-                    noise_tape, dump_steps, progress):
+                    noise_tape, dump_steps, progress, clip_denoised=False):
         """Whole loop inside libgdx (gdx_sample_loop); yields only the final state.  Noise: a recorded tape, in-kernel
         Philox, or torch's generator -- then one `normal_()` per step in the reference's order (:532: randn_like(x) is
         empty_like(x).normal_()), drawn NOISE_BLOCK steps ahead into a tape the update kernel reads; the loop is issued
@@ -396,7 +398,8 @@ class GaussianDiffusion:
                 blk = tape[k:] if tape is not None else None
             eng.sample_loop(x, kind, mode, coef, tmap, indices[k], scale=scale, inpaint_mask=mask,
                             inpaint_motion=motion, noise_tape=blk, const_noise=const_noise, philox_seed=philox_seed,
-                            sample_offset=sample_offset, dump=dump, dump_steps=dump_steps, run_steps=nb, k_base=k)
+                            sample_offset=sample_offset, dump=dump, dump_steps=dump_steps, run_steps=nb, k_base=k,
+                            clip_denoised=clip_denoised)
             k += nb
             if bar is not None:
                 th.cuda.current_stream(x.device).synchronize()

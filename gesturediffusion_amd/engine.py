@@ -140,7 +140,7 @@ class Engine:
 
     def sample_loop(self, x, kind, mode, coef, timestep_map, first_index, scale=None, inpaint_mask=None,
                     inpaint_motion=None, noise_tape=None, const_noise=False, philox_seed=0, sample_offset=0,
-                    dump=None, dump_steps=None, run_steps=0, k_base=0):
+                    dump=None, dump_steps=None, run_steps=0, k_base=0, clip_denoised=False):
         """x is updated in place (x_T in, final sample out).  run_steps / k_base: one block of a loop (gdx.h)."""
         tmap = np.ascontiguousarray(np.asarray(timestep_map, dtype=np.int64))
         ds = np.ascontiguousarray(np.asarray(dump_steps if dump_steps is not None else [], dtype=np.int32))
@@ -153,7 +153,7 @@ class Engine:
                           const_noise=int(const_noise), philox_seed=philox_seed, sample_offset=sample_offset,
                           dump=dump.data_ptr() if dump is not None else None,
                           dump_steps=ds.ctypes.data if len(ds) else None, n_dump=len(ds), run_steps=run_steps,
-                          k_base=k_base)
+                          k_base=k_base, clip_denoised=int(bool(clip_denoised)))
         _lib.check(self.lib.gdx_sample_loop(self.handle, C.byref(a), _stream(x.device)), self.lib)
         self._keep_loop = (tmap, ds)
 
@@ -179,7 +179,7 @@ class Engine:
 # ---------------------------------------------------------------------- standalone kernels
 def sampler_update(kind, coef, x, x0_cond, out, t=None, step_index=0, x0_uncond=None, scale=None, inpaint_mask=None,
                    inpaint_motion=None, noise=None, const_noise=False, philox_seed=0, sample_offset=0, rng_step=0,
-                   pred_xstart=None, cond_grad=None, cond_coef=None):
+                   pred_xstart=None, cond_grad=None, cond_coef=None, clip_denoised=False):
     lib = _lib.load()
     B, J, F, T = x.shape
     a = _lib.UpdateArgs(kind=kind, batch=B, njoints=J * F, frames=T, coef=coef.data_ptr(),
@@ -192,7 +192,8 @@ def sampler_update(kind, coef, x, x0_cond, out, t=None, step_index=0, x0_uncond=
                         philox_seed=philox_seed, sample_offset=sample_offset, rng_step=rng_step, out=out.data_ptr(),
                         pred_xstart=pred_xstart.data_ptr() if pred_xstart is not None else None,
                         cond_grad=cond_grad.data_ptr() if cond_grad is not None else None,
-                        cond_coef=cond_coef.data_ptr() if cond_coef is not None else None)
+                        cond_coef=cond_coef.data_ptr() if cond_coef is not None else None,
+                        clip_denoised=int(bool(clip_denoised)))
     _lib.check(lib.gdx_sampler_update(C.byref(a), _stream(x.device)), lib)
     return out
 

@@ -116,6 +116,7 @@ int gdx_check_guards(gdx_handle_t h, int64_t* bad_bytes, int32_t* first_bad_zone
  * cfg_sampler.py:28).  Per element, with per-sample fp32 coefficient row c = coef[idx]:
  *   x0  = x0_cond                       or  u + scale*(c - u)   when x0_uncond != NULL
  *   x0  = x0*(1-m) + motion*m           when inpaint_mask != NULL
+ *   x0  = clamp(x0, -1, 1)              when clip_denoised
  *   P   : out = (c[0]*x0 + c[1]*x) + c[2]*z
  *   DDIM: eps = (c[0]*x - x0)/c[1];  out = (x0*c[2] + c[3]*eps) + c[4]*z
  * with separately rounded products/sums (no FMA contraction), matching torch's op order.
@@ -148,6 +149,7 @@ typedef struct {
      *         cond_coef[idx] = sqrt(1 - alpha_bar) in fp32, device [num_steps]) */
     const float* cond_grad;    /* [B,J,1,T] gradient returned by cond_fn */
     const float* cond_coef;
+    int32_t clip_denoised;     /* x0 = clamp(x0, -1, 1) after the CFG / inpainting blends (process_xstart, :349-355) */
 } gdx_update_args_t;
 int gdx_sampler_update(const gdx_update_args_t* a, void* stream);
 
@@ -245,6 +247,7 @@ typedef struct {
      * always starts at THIS call's first step. */
     int32_t run_steps;
     int32_t k_base;
+    int32_t clip_denoised;     /* clamp x0 to [-1, 1] each step, as in the update arguments; the callers of the reference pass False */
 } gdx_loop_args_t;
 int gdx_sample_loop(gdx_handle_t h, const gdx_loop_args_t* a, void* stream);
 

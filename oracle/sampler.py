@@ -56,8 +56,17 @@ def ddim_reverse_step(tab, x0, x, t):
     return x0 * torch.sqrt(ab_next) + torch.sqrt(1 - ab_next) * eps
 
 
+def process_xstart(x0, clip_denoised=False, denoised_fn=None):
+    """reference gaussian_diffusion.py:349-355 (applied to the model output AFTER the inpainting blend :307-311)."""
+    if denoised_fn is not None:
+        x0 = denoised_fn(x0)
+    if clip_denoised:
+        x0 = x0.clamp(-1, 1)
+    return x0
+
+
 def sample_loop(model_fn, tab, tmap, shape, tape, y, kind="p", eta=0.0, skip_timesteps=0,
-                init_image=None, const_noise=False, dump_steps=None):
+                init_image=None, const_noise=False, dump_steps=None, clip_denoised=False, denoised_fn=None):
     """Drive `model_fn(x, mapped_t, y) -> x0` through the whole reverse process.
 
     tape: list/tensor of N+1 noise tensors, tape[0] = x_T, tape[1+k] = z of the k-th
@@ -76,7 +85,7 @@ def sample_loop(model_fn, tab, tmap, shape, tape, y, kind="p", eta=0.0, skip_tim
     dump = []
     for k, i in enumerate(indices):
         t = torch.tensor([i] * B)
-        x0 = inpaint(model_fn(img, map_tensor[t], y), y)
+        x0 = process_xstart(inpaint(model_fn(img, map_tensor[t], y), y), clip_denoised, denoised_fn)
         z = tape[1 + k]
         if kind == "p":
             if const_noise:

@@ -290,6 +290,49 @@ def gen_plms_tiny(mods, out):
         np.savez_compressed(os.path.join(out, f"plms_{arch}_tiny.npz"), **d)
 
 
+def denoised_fn_fixture(x):
+    """Deterministic stand-in for a user's denoised_fn (process_xstart, gaussian_diffusion.py:349-355)."""
+    return 1.5 * torch.tanh(x) + 0.05
+
+
+def gen_clip_tiny(mods, out):
+    """p_sample_loop / ddim_sample_loop with clip_denoised=True and with a denoised_fn (process_xstart :349-355: the
+    inpainting blend :307-311 comes first, then denoised_fn, then the clamp), same tiny models / inputs / noise tape as
+    loops_{arch}_tiny.npz (outputs only)."""
+    ref_cfg, gd, rs = mods[2], mods[3], mods[4]
+    for arch in ("mdm", "mdm_old"):
+        cfg = tiny_cfg(arch)
+        sd = init_state_dict(cfg, seed=2, perturb=True)
+        B, T = 3, 20
+        _, seedp, mfcc = synthetic_inputs(cfg, B, T, seed=5)
+        m = build_ref_model(mods, cfg, sd)
+        cfgm = ref_cfg.ClassifierFreeSampleModel(m)
+        g = torch.Generator().manual_seed(1234)
+        shape = (B, cfg["njoints"], 1, T)
+        tape = torch.randn(22, *shape, generator=g)
+        torch.randn(*shape, generator=g)                      # (init_image of the loops fixture: keeps the generator in step)
+        mask = torch.zeros(shape, dtype=torch.bool)
+        mask[..., :5] = True
+        mask[:, :4] = True
+        motion = torch.randn(*shape, generator=g) * 2.0       # beyond [-1, 1]: the clamp acts on the inpainted values too
+        scale = torch.tensor([2.5, 1.0, 0.0])
+        y = {"seed": seedp, "mfcc": mfcc}
+        d = {"inpainted_motion": motion.numpy()}
+
+        def run(kind, respacing, model, yy, **kw):
+            df = make_diffusion(gd, rs, respacing)
+            fn = df.p_sample_loop if kind == "p" else df.ddim_sample_loop
+            with TapeNoise(tape[1:]):
+                return fn(model, shape, noise=tape[0].clone(), model_kwargs={"y": yy}, progress=False, **kw).numpy()
+        yin = dict(y, inpainting_mask=mask, inpainted_motion=motion)
+        d["p20_clip"] = run("p", [20], m, y, clip_denoised=True)
+        d["p20_clip_cfg_inpaint"] = run("p", [20], cfgm, dict(yin, scale=scale), clip_denoised=True)
+        d["ddim10_clip"] = run("ddim", "ddim10", m, y, clip_denoised=True)
+        d["p20_dfn_inpaint"] = run("p", [20], m, yin, clip_denoised=False, denoised_fn=denoised_fn_fixture)
+        d["p20_dfn_clip"] = run("p", [20], m, y, clip_denoised=True, denoised_fn=denoised_fn_fixture)
+        np.savez_compressed(os.path.join(out, f"clip_{arch}_tiny.npz"), **d)
+
+
 def cond_fn_fixture(x, t, **kwargs):
     """Deterministic stand-in for a classifier gradient (the reference has no classifier): smooth in x, depends on t."""
     return 0.05 * torch.sin(x) * (1.0 + t.view(-1, 1, 1, 1).float() / 1000.0)
@@ -514,12 +557,12 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--ref", default="/root/reference")
     ap.add_argument("--out", default=os.path.join(REPO, "tests", "golden"))
-    ap.add_argument("--only", default="", help="comma-separated subset: schedule,forward,loops,plms,losses,guided,collate,chunks,real,negative,keys")
+    ap.add_argument("--only", default="", help="comma-separated subset: schedule,forward,loops,plms,losses,guided,clip,collate,chunks,real,negative,keys")
     args = ap.parse_args()
     os.makedirs(args.out, exist_ok=True)
     torch.set_num_threads(8)
     mods = import_reference(args.ref)
-    gens = {"schedule": gen_schedule, "forward": gen_forward_tiny, "loops": gen_loops_tiny, "plms": gen_plms_tiny, "losses": gen_losses_tiny, "guided": gen_guided_tiny,
+    gens = {"schedule": gen_schedule, "forward": gen_forward_tiny, "loops": gen_loops_tiny, "plms": gen_plms_tiny, "losses": gen_losses_tiny, "guided": gen_guided_tiny, "clip": gen_clip_tiny,
             "collate": gen_collate, "chunks": gen_chunks_tiny, "real": gen_real_shapes, "negative": gen_negative, "keys": gen_state_dict_keys}
     for name in (args.only.split(",") if args.only else gens):
         gens[name](mods, args.out)

@@ -143,6 +143,34 @@ def test_condition_cache_does_not_alias_freed_views():
     assert not torch.equal(outs[0], outs[1]) and not torch.equal(outs[1], outs[2])
 
 
+@pytest.mark.parametrize("arch", ["mdm", "mdm_old"])
+@pytest.mark.parametrize("name", ["p20_clip", "p20_clip_cfg_inpaint", "ddim10_clip", "p20_dfn_inpaint", "p20_dfn_clip"])
+@pytest.mark.parametrize("fused", [True, False])
+def test_clip_denoised_and_denoised_fn_vs_reference_golden(arch, name, fused):
+    """process_xstart (reference gaussian_diffusion.py:349-355) against the reference's own loops: the clamp runs inside the
+    update kernel (fused loop and step-wise protocol alike), a user's denoised_fn between two kernel passes (blend, then
+    clamp + update); with a denoised_fn the loop is step-wise whatever `fused` says."""
+    from gesturediffusion_amd.model.cfg_sampler import ClassifierFreeSampleModel
+    from test_oracle_golden import clip_case_inputs
+    from conftest import weights_from
+    g = load_golden(f"loops_{arch}_tiny.npz")
+    gc = load_golden(f"clip_{arch}_tiny.npz")
+    d = dev()
+    m = build_model(arch, TINY, weights_from(g))
+    tape = torch.from_numpy(g["tape"]).to(d)
+    y = {"seed": torch.from_numpy(g["seed"]).to(d), "mfcc": torch.from_numpy(g["mfcc"]).to(d)}
+    extra, kw = clip_case_inputs(g, gc, name)
+    y.update({k: v.to(d) for k, v in extra.items()})
+    model = ClassifierFreeSampleModel(m) if "cfg" in name else m
+    df, fn = (_diffusion([20]), "p_sample_loop") if name.startswith("p20") else (_diffusion("ddim10"), "ddim_sample_loop")
+    shape = tuple(tape[0].shape)
+    if fused:
+        r = getattr(df, fn)(model, shape, noise_tape=tape, model_kwargs={"y": y}, **kw)
+    else:
+        r = getattr(df, fn)(model, shape, noise_tape=tape, model_kwargs={"y": y}, fused=False, **kw)
+    assert rel_err(r.cpu(), gc[name]) < LOOP_TOL, name
+
+
 # ------------------------------------------------------------------------------------------------ full-size configs
 def test_config5_fp16_per_gpu_share_rows_match_single_sample_and_oracle():
     """BASELINE config 5 at its per-GPU share (V2, J=498, d=1024, T=520, fp16 mode, B=16 = 128 / 8 GPUs): the kernels this

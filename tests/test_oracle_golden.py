@@ -130,6 +130,48 @@ def test_loops_tiny(arch, name):
     assert rel_err(r, g[name]) < 2e-5, name
 
 
+CLIP = ["p20_clip", "p20_clip_cfg_inpaint", "ddim10_clip", "p20_dfn_inpaint", "p20_dfn_clip"]
+
+
+def denoised_fn_fixture(x):
+    """Same function as oracle/tools/make_golden.py::denoised_fn_fixture (the user's callable of the fixture)."""
+    return 1.5 * torch.tanh(x) + 0.05
+
+
+def clip_case_inputs(g, gc, name):
+    """(y additions, loop kwargs) of a clip_{arch}_tiny.npz case; shared with the GPU test."""
+    y, kw = {}, {}
+    if "cfg" in name:
+        y["scale"] = torch.from_numpy(g["scale"])
+    if "inpaint" in name:
+        y["inpainting_mask"] = torch.from_numpy(g["inpainting_mask"])
+        y["inpainted_motion"] = torch.from_numpy(gc["inpainted_motion"])
+    kw["clip_denoised"] = "clip" in name
+    if "dfn" in name:
+        kw["denoised_fn"] = denoised_fn_fixture
+    return y, kw
+
+
+@pytest.mark.parametrize("arch", ["mdm", "mdm_old"])
+@pytest.mark.parametrize("name", CLIP)
+def test_clip_denoised_and_denoised_fn_loops(arch, name):
+    """process_xstart (reference gaussian_diffusion.py:349-355): clamp and user callable, after the inpainting blend."""
+    g = load_golden(f"loops_{arch}_tiny.npz")
+    gc = load_golden(f"clip_{arch}_tiny.npz")
+    p = weights_from(g)
+    cfg = dict(TINY, arch=arch)
+    tape = torch.from_numpy(g["tape"])
+    y = {"seed": torch.from_numpy(g["seed"]), "mfcc": torch.from_numpy(g["mfcc"])}
+    extra, kw = clip_case_inputs(g, gc, name)
+    y.update(extra)
+    fn = (lambda x, t, yy: omf.cfg_forward(p, cfg, x, t, yy)) if "cfg" in name else (lambda x, t, yy: omf.forward(p, cfg, x, t, yy))
+    resp, kind = ([20], "p") if name.startswith("p20") else ("ddim10", "ddim")
+    tab, tmap = osch.make_tables("cosine", 1000, resp)
+    with torch.no_grad():
+        r = osamp.sample_loop(fn, tab, tmap, tape[0].shape, tape, y, kind=kind, **kw)
+    assert rel_err(r, gc[name]) < 2e-5, name
+
+
 PLMS = {"plms10_o2": (2, {}), "plms10_o3": (3, {}), "plms10_o4_cfg": (4, {}), "plms10_o2_inpaint": (2, {}),
         "plms10_o2_init_skip": (2, {"skip_timesteps": 3})}
 
