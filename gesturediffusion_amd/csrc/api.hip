@@ -1159,9 +1159,14 @@ extern "C" int gdx_bench_gemm_f16(int32_t M, int32_t N, int32_t K, int32_t gelu,
             g2_dbg_buf = dd;
             (void)launch_gemmh(p, s);
             g2_dbg_buf = nullptr;
-            unsigned long long hh[8] = {0};
-            (void)hipMemcpyAsync(hh, dd, 64, hipMemcpyDeviceToHost, s);
+            unsigned long long hh[16] = {0};
+            (void)hipMemcpyAsync(hh, dd, 128, hipMemcpyDeviceToHost, s);
             (void)hipStreamSynchronize(s);
+            if (hh[12] && hh[11])
+                fprintf(stderr, "[gemmh8 stamps] block 0, wave 0: %llu tiles, loop %.1f us at %.2f GHz; per tile: drain before the stores %.0f cycles, "
+                        "epilogue (bias, convert, stores issued) %.0f; step pair in steady state %.0f cycles (%llu pairs), first two pairs after an "
+                        "epilogue %.0f cycles each\n", hh[12], hh[5] / 100.0, hh[5] ? (double)hh[4] / (hh[5] * 10.0) : 0.0,
+                        (double)hh[6] / hh[12], (double)hh[7] / hh[12], (double)hh[10] / hh[11], hh[11], hh[9] ? (double)hh[8] / hh[9] : 0.0);
             if (hh[3])
                 fprintf(stderr, "[gemmh stamps] loader wave, block 0: %llu steps; per step: issue %.0f, vmcnt wait %.0f, barrier wait %.0f, total %.0f cycles; loop %.1f us -> s_memtime at %.2f GHz\n",
                         hh[3], (double)hh[0] / hh[3], (double)hh[1] / hh[3], (double)hh[2] / hh[3], (double)hh[4] / hh[3],

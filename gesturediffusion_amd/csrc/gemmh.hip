@@ -62,8 +62,20 @@ __device__ __forceinline__ f32x2 gelu2(f32x2 x) {
     return h + h * (z * pl);
 }
 
+// Output-column map of a wave's NBW accumulator blocks (swapped MFMA: quad q = lane >> 4 of the accumulator, block j,
+// register e).  The four quads are 8 columns apart (4 for NBW = 1) and a PAIR of blocks (j, j+1) gives a lane 8
+// consecutive columns, so one 16-byte fp16 store instruction writes 64 contiguous bytes per output row (the four quads
+// side by side) -- with the first mapping (q * 4 NBW + 4 j + e) the 256-column tile's stores were four separate 16-byte
+// pieces per row and instruction.  The W rows are dealt to the MFMA's A-operand rows by the same map (fragment reads, DMA).
+template <int NBW>
+struct ColMap {
+    static constexpr int QS = NBW == 1 ? 4 : 8;                                  // columns between quads
+    static constexpr int QSH = NBW == 1 ? 2 : 3;                                 // log2(QS): the W rows' swizzle shift
+    __host__ __device__ static constexpr int blk(int j) { return NBW == 1 ? 0 : (j >> 1) * 32 + (j & 1) * 4; }
+};
+
 // Epilogue of one wave: its MB x NBW accumulator blocks (swapped MFMA: lane & 15 = row inside a 16-row block, registers
-// = columns q*4*NBW + j*4 + e) -> bias / R / V / GELU -> fp32 and / or fp16 stores.  (m0, nw0) = first row / column of
+// = columns ColMap: q*QS + blk(j) + e) -> bias / R / V / GELU -> fp32 and / or fp16 stores.  (m0, nw0) = first row / column of
 // the wave's sub-tile.  Clears the accumulators.
 // The output / residual pointers are restrict-qualified PARAMETERS so that, after inlining, the compiler may hoist the
 // R / V loads of later rows above the stores of earlier ones (they never alias: different workspace buffers); through
@@ -72,11 +84,12 @@ template <int MB, int NBW>
 __device__ __forceinline__ void wave_epilogue_impl(const GemmHParams& p, f32x4 (&acc)[MB][NBW], const float* bias_lds,
                                                    int m0, int nw0, int l15, int lq, const float* __restrict__ pR,
                                                    const float* __restrict__ pV, float* __restrict__ pC32,
-                                                   _Float16* __restrict__ pC16) {
-    const int nb = nw0 + lq * (4 * NBW);
-    f32x4 bv[NBW];
+                                                   _Float16* __restrict__ pC16, const f32x4* bv_in = nullptr) {
+    using CM = ColMap<NBW>;
+    const int nb = nw0 + lq * CM::QS;
+    f32x4 bv[NBW];                                                // bias: the LDS copy, or (bias_lds == nullptr) registers the caller loaded
 #pragma unroll
-    for (int j = 0; j < NBW; ++j) bv[j] = *reinterpret_cast<const f32x4*>(&bias_lds[nb + j * 4]);
+    for (int j = 0; j < NBW; ++j) bv[j] = bias_lds ? *reinterpret_cast<const f32x4*>(&bias_lds[nb + CM::blk(j)]) : bv_in[j];
 #pragma unroll
     for (int i = 0; i < MB; ++i) {
         const int m = m0 + i * 16 + l15;
@@ -95,11 +108,11 @@ __device__ __forceinline__ void wave_epilogue_impl(const GemmHParams& p, f32x4 (
             }
             if (pR) {
 #pragma unroll
-                for (int j = 0; j < NBW; ++j) v[j] += *reinterpret_cast<const f32x4*>(&pR[ro * p.ldr + nb + j * 4]);
+                for (int j = 0; j < NBW; ++j) v[j] += *reinterpret_cast<const f32x4*>(&pR[ro * p.ldr + nb + CM::blk(j)]);
             }
             if (pV) {
 #pragma unroll
-                for (int j = 0; j < NBW; ++j) v[j] += *reinterpret_cast<const f32x4*>(&pV[(long)bs * p.ldv + nb + j * 4]);
+                for (int j = 0; j < NBW; ++j) v[j] += *reinterpret_cast<const f32x4*>(&pV[(long)bs * p.ldv + nb + CM::blk(j)]);
             }
             if (p.gelu) {
 #pragma unroll
@@ -110,7 +123,7 @@ __device__ __forceinline__ void wave_epilogue_impl(const GemmHParams& p, f32x4 (
             }
             if (pC32) {
 #pragma unroll
-                for (int j = 0; j < NBW; ++j) *reinterpret_cast<f32x4*>(&pC32[ro * p.ldc32 + nb + j * 4]) = v[j];
+                for (int j = 0; j < NBW; ++j) *reinterpret_cast<f32x4*>(&pC32[ro * p.ldc32 + nb + CM::blk(j)]) = v[j];
             }
             if (pC16) {
                 _Float16* cp = pC16 + ro * p.ldc16 + nb;
@@ -120,7 +133,7 @@ __device__ __forceinline__ void wave_epilogue_impl(const GemmHParams& p, f32x4 (
                 } else {
 #pragma unroll
                     for (int j = 0; j < NBW; j += 2)
-                        *reinterpret_cast<f16x8*>(cp + j * 4) =
+                        *reinterpret_cast<f16x8*>(cp + CM::blk(j)) =
                             f16x8{(_Float16)v[j][0],     (_Float16)v[j][1],     (_Float16)v[j][2],     (_Float16)v[j][3],
                                   (_Float16)v[j + 1][0], (_Float16)v[j + 1][1], (_Float16)v[j + 1][2], (_Float16)v[j + 1][3]};
                 }
@@ -131,8 +144,8 @@ __device__ __forceinline__ void wave_epilogue_impl(const GemmHParams& p, f32x4 (
 
 template <int MB, int NBW>
 __device__ __forceinline__ void wave_epilogue(const GemmHParams& p, f32x4 (&acc)[MB][NBW], const float* bias_lds, int m0,
-                                              int nw0, int l15, int lq) {
-    wave_epilogue_impl<MB, NBW>(p, acc, bias_lds, m0, nw0, l15, lq, p.R, p.V, p.C32, p.C16);
+                                              int nw0, int l15, int lq, const f32x4* bv_in = nullptr) {
+    wave_epilogue_impl<MB, NBW>(p, acc, bias_lds, m0, nw0, l15, lq, p.R, p.V, p.C32, p.C16, bv_in);
 }
 
 // scheduling recipe for one K step: one ds_read after every PER MFMAs over the first ~2/3 of the NMM MFMAs, the
@@ -157,7 +170,7 @@ __global__ __launch_bounds__(512, 1) void gemmh_kernel(const GemmHParams p, cons
     constexpr int A_BYTES = BM * 64, W_BYTES = BN * 64, STAGE_BYTES = A_BYTES + W_BYTES;
     constexpr int A_P = A_BYTES / 1024, P = STAGE_BYTES / 1024;   // 1 KiB DMA pieces (16 rows x 64 B) per slab
     constexpr int PW = (P + 3) / 4;                               // pieces per loader wave per slab
-    constexpr int SHW = NBW == 4 ? 4 : NBW == 2 ? 3 : 2;          // log2(columns per accumulator q group)
+    constexpr int SHW = ColMap<NBW>::QSH;                         // log2(columns between accumulator quads)
     constexpr int VM_STEP = (NST - 3) * PW;                       // DMA pieces younger than the slab a step waits for
     static_assert(NBW == 1 || NBW == 2 || NBW == 4, "NBW must be 1, 2 or 4");
     static_assert(NST >= 3 && VM_STEP < 64, "ring depth / vmcnt range");
@@ -268,12 +281,12 @@ __global__ __launch_bounds__(512, 1) void gemmh_kernel(const GemmHParams p, cons
         for (int j = 0; j < NBW; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int gq = (-(l15 >> 2)) & 3;
     const int a_off = l15 * 64 + ((lq ^ gq) * 16);                                   // activation fragment, bytes
-    const int w_off = A_BYTES + (wave * WN + (l15 >> 2) * (4 * NBW) + (l15 & 3)) * 64 + ((lq ^ gq) * 16);
+    const int w_off = A_BYTES + (wave * WN + (l15 >> 2) * ColMap<NBW>::QS + (l15 & 3)) * 64 + ((lq ^ gq) * 16);
     f16x8 fa0[MB], fw0[NBW], fa1[MB], fw1[NBW];
     auto rd = [&](f16x8 (&fa)[MB], f16x8 (&fw)[NBW], int stage) {
         const char* S = smem + stage * STAGE_BYTES;
 #pragma unroll
-        for (int j = 0; j < NBW; ++j) fw[j] = *reinterpret_cast<const f16x8*>(S + w_off + j * 256);
+        for (int j = 0; j < NBW; ++j) fw[j] = *reinterpret_cast<const f16x8*>(S + w_off + ColMap<NBW>::blk(j) * 64);
 #pragma unroll
         for (int i = 0; i < MB; ++i) fa[i] = *reinterpret_cast<const f16x8*>(S + a_off + i * 1024);
     };
@@ -348,7 +361,7 @@ __global__ __launch_bounds__(512, 1) void gemmh8_kernel(const GemmHParams p, con
     constexpr int MB = 8, NBW = 4, WM = 128, WN = 64, BM = 256, BN = 256;
     constexpr int A_BYTES = BM * 64, W_BYTES = BN * 64, STAGE_BYTES = A_BYTES + W_BYTES;      // 32 KiB
     constexpr int A_P = A_BYTES / 1024, P = STAGE_BYTES / 1024, PW = P / 8;                    // 4 pieces per wave
-    constexpr int SHW = 4;
+    constexpr int SHW = ColMap<NBW>::QSH;
     constexpr int VM_STEP = (NST - 3) * PW;
     static_assert(NST >= 4 && P % 8 == 0, "ring depth");
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -421,12 +434,12 @@ __global__ __launch_bounds__(512, 1) void gemmh8_kernel(const GemmHParams p, con
         for (int j = 0; j < NBW; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int gq = (-(l15 >> 2)) & 3;
     const int a_off = (wr * WM + l15) * 64 + ((lq ^ gq) * 16);
-    const int w_off = A_BYTES + (wc * WN + (l15 >> 2) * (4 * NBW) + (l15 & 3)) * 64 + ((lq ^ gq) * 16);
+    const int w_off = A_BYTES + (wc * WN + (l15 >> 2) * ColMap<NBW>::QS + (l15 & 3)) * 64 + ((lq ^ gq) * 16);
     f16x8 fa0[MB], fw0[NBW], fa1[MB], fw1[NBW];
     auto rd = [&](f16x8 (&fa)[MB], f16x8 (&fw)[NBW], int stage) {
         const char* S = smem + stage * STAGE_BYTES;
 #pragma unroll
-        for (int j = 0; j < NBW; ++j) fw[j] = *reinterpret_cast<const f16x8*>(S + w_off + j * 256);
+        for (int j = 0; j < NBW; ++j) fw[j] = *reinterpret_cast<const f16x8*>(S + w_off + ColMap<NBW>::blk(j) * 64);
 #pragma unroll
         for (int i = 0; i < MB; ++i) fa[i] = *reinterpret_cast<const f16x8*>(S + a_off + i * 1024);
     };
@@ -473,8 +486,13 @@ __global__ __launch_bounds__(512, 1) void gemmh8_kernel(const GemmHParams p, con
     rd(fa0, fw0, 0);
     unsigned long long t0 = 0, r0 = 0;
     if (dbg) { t0 = __builtin_amdgcn_s_memtime(); r0 = __builtin_amdgcn_s_memrealtime(); }
+    // diagnostic stamps (GDX_GEMM_DEBUG only): where a tile's cycles go -- the drain in front of the stores, the stores,
+    // the step pairs right after an epilogue and the steady-state step pairs
+    unsigned long long d_drain = 0, d_store = 0, d_post = 0, d_steady = 0, n_post = 0, n_steady = 0, tp = 0;
+    int since_epi = 100;
     {
         for (int g = 0; g < total; g += 2) {
+            if (dbg) tp = __builtin_amdgcn_s_memtime();
             int nstage = stage == NST - 1 ? 0 : stage + 1;
             issue(wst);                                           // slab g+NST-1 -> the stage freed by the last barrier
             wst = wst == NST - 1 ? 0 : wst + 1;
@@ -510,19 +528,39 @@ __global__ __launch_bounds__(512, 1) void gemmh8_kernel(const GemmHParams p, con
                 const int tile = lid + tile_i * G;
                 ++tile_i;
                 __builtin_amdgcn_sched_barrier(0);
+                unsigned long long te0 = 0, te1 = 0;
+                if (dbg) te0 = __builtin_amdgcn_s_memtime();
                 wait_vm_h<0>();
                 __builtin_amdgcn_s_waitcnt(0xc07f);
                 __builtin_amdgcn_s_barrier();
                 asm volatile("" ::: "memory");
                 __builtin_amdgcn_sched_barrier(0);
+                if (dbg) te1 = __builtin_amdgcn_s_memtime();
                 wave_epilogue<MB, NBW>(p, acc, bias_lds, (tile / ntn) * BM + wr * WM, (tile % ntn) * BN + wc * WN, l15, lq);
                 tile_base(tile_i + 1, a_nxt, w_nxt);              // the DMA stream is already inside tile tile_i
                 skip_wait = true;
+                if (dbg) {
+                    const unsigned long long te2 = __builtin_amdgcn_s_memtime();
+                    d_drain += te1 - te0; d_store += te2 - te1;
+                    tp = te2;                                     // the pair's own time ends where the epilogue began
+                    since_epi = -1;
+                }
             } else {
                 step_sync();
             }
             stage = nstage;
+            if (dbg) {
+                const unsigned long long tn = __builtin_amdgcn_s_memtime();
+                if (since_epi >= 0) {
+                    if (since_epi < 2) { d_post += tn - tp; ++n_post; } else { d_steady += tn - tp; ++n_steady; }
+                }
+                ++since_epi;
+            }
         }
+    }
+    if (dbg && blockIdx.x == 0 && tid == 0) {
+        dbg[6] = d_drain; dbg[7] = d_store; dbg[8] = d_post; dbg[9] = n_post; dbg[10] = d_steady; dbg[11] = n_steady;
+        dbg[12] = (unsigned long long)my_tiles;
     }
     if (dbg && blockIdx.x == 0 && tid == 0) {                     // diagnostic stamps (GDX_GEMM_DEBUG)
         dbg[4] = __builtin_amdgcn_s_memtime() - t0;
@@ -547,6 +585,269 @@ static hipError_t launch_cfg_h8(const GemmHParams& p, int num_cus, hipStream_t s
     const int ntiles = ntm * ntn;
     const int grid = ntiles < num_cus ? ntiles : num_cus;
     hipLaunchKernelGGL((gemmh8_kernel<NST>), dim3(grid), dim3(512), lds, s, p, ntn, ntiles, g2_dbg_buf);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// 256 x 256 tile, eight MFMA waves, operands staged as WHOLE 128-byte lines.
+//
+// What bounds the kernel above (stamps, GDX_GEMM_DEBUG, M = 66 688, N = K = 1 024, clock 1.6 GHz under load): a pair of
+// K steps takes 2 620 cycles in steady state against 2 048 of MFMA issue -- 64 KiB staged per pair = 25 B/clk, the rate
+// the CU's vector-memory pipe sustains for LDS-DMA pieces that take 64 bytes from each of 16 rows (tools/probe/dma_probe:
+// 49 GB/s per CU; 78 GB/s when a piece takes 128 bytes from each of 8 rows, i.e. whole lines).  With 64-byte LDS rows
+// (one 32-deep K slab per stage) every line is fetched twice, half at a time.  Here a stage UNIT is one operand's 64-deep
+// K slab: 256 rows x 128 B = 32 KiB, a DMA piece is 8 rows x 128 B, and the CU's 160 KiB of LDS hold five units in one
+// ring that alternates operands:  X_0 = A_0, X_1 = W_0, X_2 = A_1, X_3 = W_1, ...  (unit n lives in slot n % 5).
+// A 64-deep slab j is two MFMA k-steps (h = 0, 1: bytes 64 h .. 64 h + 63 of each row); fragments run one step ahead in
+// registers as before, so A_j and W_j are last read during step (j, 0) and their slots are free from step (j, 1):
+//     step (j, 0): issue A_{j+2}   (first read during step (j+1, 1): three steps ahead)
+//     step (j, 1): issue W_{j+2}   (first read during step (j+1, 1): two steps ahead, the old ring's distance)
+// 4 pieces per wave and step, as before.  Counted waits: end of (j, 0) needs slab j+1 landed -- only A_{j+2} is younger
+// (vmcnt 4); the end of (j, 1) needs nothing new.  Bias is read from global memory (no LDS left), in front of the
+// drain that precedes the stores.  LDS rows are 128 B = 8 chunks of 16 B; chunk c of row r is stored at
+// c ^ (((r >> 1) ^ (r >> 3)) & 7), which makes every ds_read_b128 lane group touch all 64 banks once for both operands'
+// row maps (searched by brute force over XOR-linear maps; tools/probe notes in DESIGN.md).  For a lane the swizzle is
+// (lane part) ^ (a compile-time even constant K in {0, 2, 4, 6}), so four lane offsets per operand cover every read.
+// Summation order per output element is unchanged (k ascending by 32), so results are bit-identical to the kernel above.
+__global__ __launch_bounds__(512, 1) void gemmh8b_kernel(const GemmHParams p, const int ntn, const int ntiles,
+                                                         unsigned long long* dbg) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    constexpr int MB = 8, NBW = 4, WM = 128, WN = 64, BM = 256, BN = 256;
+    constexpr int UNIT = 256 * 128, NU = 5;                       // 32 KiB per unit, five units
+    constexpr int PW = 4;                                         // pieces (8 rows x 128 B) per wave and unit
+    using CM = ColMap<NBW>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid) >> 6;
+    const int wr = wave >> 2, wc = wave & 3;
+    const int lane = tid & 63;
+    const int l15 = lane & 15, lq = lane >> 4;
+    const int G = gridDim.x;
+    int lid;
+    {
+        const int bid = blockIdx.x, q = G >> 3, r = G & 7, xcd = bid & 7, idx = bid >> 3;
+        lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int my_tiles = lid < ntiles ? (ntiles - lid + G - 1) / G : 0;
+    const int nk = p.K / 64;                                      // 64-deep slabs per tile (>= 4)
+    const int total = my_tiles * nk;
+    if (total == 0) return;
+
+    // ---- DMA: piece i of a unit = rows 8 (wave + 8 i) .. + 7; lane -> row lane >> 3, LDS chunk lane & 7, which holds the
+    //      row's chunk (lane & 7) ^ f(row).  f(row) does not depend on i (rows 64 apart), so ONE per-lane offset per operand.
+    const auto rsrcA = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(p.A), (short)0, p.a_bytes, 0x00020000);
+    const auto rsrcW = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(p.W), (short)0, p.w_bytes, 0x00020000);
+    const int drow = wave * 8 + (lane >> 3);
+    const int dsw = ((drow >> 1) ^ (drow >> 3)) & 7;
+    const int voffA = drow * p.lda * 2 + (((lane & 7) ^ dsw) * 16);
+    const int voffW = drow * p.ldw * 2 + (((lane & 7) ^ dsw) * 16);
+    auto tile_base = [&](int ti, int& a_so, int& w_so) {
+        const int t = ti < my_tiles ? ti : my_tiles - 1;          // past the end: harmless re-reads
+        const int tile = lid + t * G;
+        a_so = (tile / ntn) * BM * p.lda * 2;
+        w_so = (tile % ntn) * BN * p.ldw * 2;
+    };
+    // The two streams run 2 slabs ahead of the MFMAs, so they cross a tile boundary before the MFMAs do: the base of the
+    // next tile is taken by a select (no branch: the DMA issue must stay in the MFMA basic block to be interleaved) and
+    // the base of the tile after next is computed once per tile, in the epilogue branch (K >= 256: a stream wraps once
+    // per tile, always after the previous tile's epilogue).
+    int a_ks = 0, w_ks = 0, a_cur, w_cur, a_nxt, w_nxt;
+    tile_base(0, a_cur, w_cur);
+    tile_base(1, a_nxt, w_nxt);
+    int a_slot = 0, w_slot = 1;                                   // slot of the next A / W unit to issue (n % 5, n += 2)
+    auto issue_A = [&]() {
+        const int so = a_cur + a_ks * 128;
+        char* sb = smem + a_slot * UNIT + wave * 1024;
+#pragma unroll
+        for (int i = 0; i < PW; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcA, (lds_ptr_t)(sb + i * 8192), 16, voffA, so + i * 64 * p.lda * 2, 0, 0);
+        a_slot = a_slot >= NU - 2 ? a_slot + 2 - NU : a_slot + 2;
+        ++a_ks;
+        const bool wrap = a_ks == nk;
+        a_ks = wrap ? 0 : a_ks;
+        a_cur = wrap ? a_nxt : a_cur;
+    };
+    auto issue_W = [&]() {
+        const int so = w_cur + w_ks * 128;
+        char* sb = smem + w_slot * UNIT + wave * 1024;
+#pragma unroll
+        for (int i = 0; i < PW; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcW, (lds_ptr_t)(sb + i * 8192), 16, voffW, so + i * 64 * p.ldw * 2, 0, 0);
+        w_slot = w_slot >= NU - 2 ? w_slot + 2 - NU : w_slot + 2;
+        ++w_ks;
+        const bool wrap = w_ks == nk;
+        w_ks = wrap ? 0 : w_ks;
+        w_cur = wrap ? w_nxt : w_cur;
+    };
+
+    f32x4 acc[MB][NBW];
+#pragma unroll
+    for (int i = 0; i < MB; ++i)
+#pragma unroll
+        for (int j = 0; j < NBW; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // ---- fragment addresses.  A row = 128 wr + 16 i + l15: swizzle = ((l15 >> 1) & 7) ^ (l15 >> 3) ^ (2 i & 7);
+    //      W row = 64 wc + 8 (l15 >> 2) + (l15 & 3) + blk(j): swizzle = (((l15 & 3) >> 1) | ((l15 >> 2 & 1) << 2)) ^ (l15 >> 2)
+    //      ^ (((j & 1) << 1) | ((j >> 1) << 2)).  Chunk of k-step h: 4 h + lq.  Lane part ^ even constant K:
+    const int laneA = lq ^ ((l15 >> 1) & 7) ^ (l15 >> 3);
+    const int laneW = lq ^ ((((l15 & 3) >> 1) | (((l15 >> 2) & 1) << 2)) ^ (l15 >> 2));
+    const int rowA = (wr * WM + l15) * 128, rowW = (wc * WN + (l15 >> 2) * CM::QS + (l15 & 3)) * 128;
+    int offA[4], offW[4];                                         // byte offsets inside a unit for K = 0, 2, 4, 6
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        offA[k] = rowA + ((laneA ^ (2 * k)) << 4);
+        offW[k] = rowW + ((laneW ^ (2 * k)) << 4);
+    }
+    f16x8 fa0[MB], fw0[NBW], fa1[MB], fw1[NBW];
+    // fragments of k-step h of the slab whose units sit at LDS byte offsets ua / uw
+    auto rd = [&](f16x8 (&fa)[MB], f16x8 (&fw)[NBW], int ua, int uw, auto h_tag) {
+        constexpr int h = decltype(h_tag)::value;
+#pragma unroll
+        for (int j = 0; j < NBW; ++j) {
+            const int K = ((4 * h) ^ (((j & 1) << 1) | ((j >> 1) << 2))) >> 1;
+            fw[j] = *reinterpret_cast<const f16x8*>(smem + uw + offW[K] + CM::blk(j) * 128);
+        }
+#pragma unroll
+        for (int i = 0; i < MB; ++i) {
+            const int K = ((4 * h) ^ ((2 * i) & 7)) >> 1;
+            fa[i] = *reinterpret_cast<const f16x8*>(smem + ua + offA[K] + i * 2048);
+        }
+    };
+    auto mm = [&](const f16x8 (&fa)[MB], const f16x8 (&fw)[NBW]) {
+#pragma unroll
+        for (int i = 0; i < MB; ++i)
+#pragma unroll
+            for (int j = 0; j < NBW; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fw[j], fa[i], acc[i][j], 0, 0, 0);
+    };
+    auto sync_wait = [&]() {                                      // end of step (j, 0): slab j+1 has landed
+        __builtin_amdgcn_sched_barrier(0);
+        wait_vm_h<PW>();
+        __builtin_amdgcn_s_waitcnt(0xc07f);                       // lgkmcnt(0)
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto sync_nowait = [&]() {
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto interleave = [&]() {                                     // 4 DMA pieces, then 12 fragment reads, among the 32 MFMAs
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);    // MFMA
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);    // VMEM read (LDS-DMA piece)
+        }
+#pragma unroll
+        for (int r = 0; r < 12; ++r) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);    // DS read
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, 12, 0);
+    };
+    using H0 = std::integral_constant<int, 0>;
+    using H1 = std::integral_constant<int, 1>;
+
+    issue_A(); issue_W(); issue_A(); issue_W();                   // A_0, W_0, A_1, W_1
+    wait_vm_h<2 * PW>();                                          // slab 0 (this wave's pieces)
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    int ks = 0, tile_i = 0, ua = 0, uw = UNIT;                    // LDS offsets of the current slab's A / W units
+    bool skip = false;
+    rd(fa0, fw0, ua, uw, H0{});
+    unsigned long long t0 = 0, r0 = 0;
+    if (dbg) { t0 = __builtin_amdgcn_s_memtime(); r0 = __builtin_amdgcn_s_memrealtime(); }
+    const int nbl = wc * WN + lq * CM::QS;                        // this lane's first column inside the tile
+    // diagnostic stamps (GDX_GEMM_DEBUG only), as in the kernel above
+    unsigned long long d_drain = 0, d_store = 0, d_post = 0, d_steady = 0, n_post = 0, n_steady = 0, tp = 0;
+    int since_epi = 100;
+    for (int g = 0; g < total; ++g) {
+        if (dbg) tp = __builtin_amdgcn_s_memtime();
+        // next slab's units: two slots on (mod 5)
+        const int una = ua >= (NU - 2) * UNIT ? ua + (2 - NU) * UNIT : ua + 2 * UNIT;
+        const int unw = uw >= (NU - 2) * UNIT ? uw + (2 - NU) * UNIT : uw + 2 * UNIT;
+        // ---- step (g, 0): MFMAs of k-half 0; fragments of k-half 1 of the same slab; A_{g+2} -> the free slot
+        issue_A();
+        rd(fa1, fw1, ua, uw, H1{});
+        mm(fa0, fw0);
+        interleave();
+        if (skip) { skip = false; sync_nowait(); } else { sync_wait(); }
+        // ---- step (g, 1): MFMAs of k-half 1; fragments of slab g+1; W_{g+2} -> A_g's slot (dead since the barrier)
+        issue_W();
+        rd(fa0, fw0, una, unw, H0{});                             // past the last slab: a stale unit, never used
+        mm(fa1, fw1);
+        interleave();
+        if (++ks == nk) {
+            // Tile end: drain the DMA queue BEFORE the stores are issued (a counted wait behind them would stall every
+            // wave, through the barrier, until they retire): everything up to W_{g+2} has then landed and the next step
+            // needs no wait.  The bias registers are loaded in front of the drain, which covers their latency.
+            ks = 0;
+            const int tile = lid + tile_i * G;
+            ++tile_i;
+            __builtin_amdgcn_sched_barrier(0);
+            f32x4 bv[NBW];
+            const float* bp = p.bias ? p.bias + (tile % ntn) * BN + nbl : nullptr;
+#pragma unroll
+            for (int j = 0; j < NBW; ++j) bv[j] = bp ? *reinterpret_cast<const f32x4*>(bp + CM::blk(j)) : f32x4{0.f, 0.f, 0.f, 0.f};
+            unsigned long long te0 = 0, te1 = 0;
+            if (dbg) te0 = __builtin_amdgcn_s_memtime();
+            wait_vm_h<0>();
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            if (dbg) te1 = __builtin_amdgcn_s_memtime();
+            wave_epilogue<MB, NBW>(p, acc, nullptr, (tile / ntn) * BM + wr * WM, (tile % ntn) * BN + wc * WN, l15, lq, bv);
+            tile_base(tile_i + 1, a_nxt, w_nxt);                  // the streams are already inside tile tile_i
+            skip = true;
+            if (dbg) {
+                const unsigned long long te2 = __builtin_amdgcn_s_memtime();
+                d_drain += te1 - te0; d_store += te2 - te1;
+                tp = te2;
+                since_epi = -1;
+            }
+        } else {
+            sync_nowait();
+        }
+        ua = una; uw = unw;
+        if (dbg) {
+            const unsigned long long tn = __builtin_amdgcn_s_memtime();
+            if (since_epi >= 0) {
+                if (since_epi < 2) { d_post += tn - tp; ++n_post; } else { d_steady += tn - tp; ++n_steady; }
+            }
+            ++since_epi;
+        }
+    }
+    if (dbg && blockIdx.x == 0 && tid == 0) {
+        dbg[6] = d_drain; dbg[7] = d_store; dbg[8] = d_post; dbg[9] = n_post; dbg[10] = d_steady; dbg[11] = n_steady;
+        dbg[12] = (unsigned long long)my_tiles;
+    }
+    if (dbg && blockIdx.x == 0 && tid == 0) {                     // diagnostic stamps (GDX_GEMM_DEBUG)
+        dbg[4] = __builtin_amdgcn_s_memtime() - t0;
+        dbg[5] = __builtin_amdgcn_s_memrealtime() - r0;
+        dbg[3] = (unsigned long long)total * 2;
+    }
+    wait_vm_h<0>();
+#endif
+}
+
+static hipError_t launch_cfg_h8b(const GemmHParams& p, int num_cus, hipStream_t s) {
+    const size_t lds = (size_t)5 * 32768;                         // all of the CU's LDS
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemmh8b_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)lds);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    const int ntm = (p.M + 255) / 256, ntn = p.N / 256;
+    const int ntiles = ntm * ntn;
+    const int grid = ntiles < num_cus ? ntiles : num_cus;
+    hipLaunchKernelGGL(gemmh8b_kernel, dim3(grid), dim3(512), lds, s, p, ntn, ntiles, g2_dbg_buf);
     return hipGetLastError();
 }
 
@@ -636,6 +937,8 @@ hipError_t launch_gemmh(const GemmHParams& p, hipStream_t s) {
     const bool ok8 = p.K >= 128 && p.N % 256 == 0 && (size_t)4 * 32768 + (size_t)p.N * 4 <= 160 * 1024;
     if (ok8 && (force_mb == 16 || (!force_mb && gh_cost(16, 4, p.M, p.N, p.K, num_cus, p.gelu != 0) < best))) {
         if (debug) fprintf(stderr, "[gemmh] M=%d N=%d K=%d -> tile 256x256 (8 MFMA waves)\n", p.M, p.N, p.K);
+        static const bool lines = getenv("GDX_GEMMH8_HALFLINES") == nullptr;   // A/B switch: the 64-byte-row ring above
+        if (lines && p.K >= 256) return launch_cfg_h8b(p, num_cus, s);
         return launch_cfg_h8(p, num_cus, s);
     }
     if (!best_mb) return hipErrorNotSupported;

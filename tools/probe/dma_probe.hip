@@ -10,13 +10,19 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 template <int N>
 __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-template <int MODE>
+// MFMA: every wave also issues the GEMM's 32 v_mfma_f32_16x16x32_f16 per step (register operands, 32 accumulators),
+// interleaved with its DMA pieces as in the kernel: does the staging stream overlap the matrix work?
+// READS: plus the kernel's 12 ds_read_b128 fragment reads per wave and step (its addresses and swizzle), feeding the MFMAs.
+// NODMA: the same without the staging stream.
+template <int MODE, bool MFMA, bool READS = false, bool NODMA = false>
 __global__ __launch_bounds__(512, 1) void probe(const _Float16* A, const _Float16* W, int M, int N, int K, int ntn, int ntiles,
-                                                float* sink) {
+                                                float* sink, int pitch) {   // pitch: bytes between consecutive rows (>= 2 K)
 #if defined(__HIP_DEVICE_COMPILE__)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid) >> 6, lane = tid & 63;
@@ -27,36 +33,74 @@ __global__ __launch_bounds__(512, 1) void probe(const _Float16* A, const _Float1
         lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
     const int my_tiles = lid < ntiles ? (ntiles - lid + G - 1) / G : 0;
-    const auto rsrcA = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(A), (short)0, M * K * 2, 0x00020000);
-    const auto rsrcW = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(W), (short)0, N * K * 2, 0x00020000);
+    const auto rsrcA = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(A), (short)0, M * pitch, 0x00020000);
+    const auto rsrcW = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(W), (short)0, N * pitch, 0x00020000);
     // a step stages 32 pieces: 16 of A (256 rows x 64 B, or 128 rows x 128 B) and 16 of W; wave w issues w, w+8, w+16, w+24
     int voff[4];
     for (int i = 0; i < 4; ++i) {
         const int piece = (wave + 8 * i) & 15;
         const int row = MODE == 1 ? piece * 8 + (lane >> 3) : piece * 16 + (lane >> 2);
         const int col = MODE == 1 ? (lane & 7) * 16 : (lane & 3) * 16;
-        voff[i] = row * K * 2 + col;
+        voff[i] = row * pitch + col;
     }
     const int nk = K / 32;                                        // 32 KiB per step in every mode
     int stage = 0;
+    const int l15 = lane & 15, lq = lane >> 4, wr = wave >> 2, wc = wave & 3;
+    const int gq = (-(l15 >> 2)) & 3;
+    const int a_off = (wr * 128 + l15) * 64 + ((lq ^ gq) * 16);
+    const int w_off = 16384 + (wc * 64 + (l15 >> 2) * 16 + (l15 & 3)) * 64 + ((lq ^ gq) * 16);
+    f32x4 acc[32];
+    f16x8 fa[8], fb[4];
+    if (MFMA) {
+        for (int i = 0; i < 32; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int i = 0; i < 8; ++i) for (int j = 0; j < 8; ++j) fa[i][j] = (_Float16)(0.001f * (tid + i + j));
+        for (int i = 0; i < 4; ++i) for (int j = 0; j < 8; ++j) fb[i][j] = (_Float16)(0.002f * (tid + 3 * i + j));
+    }
     for (int t = 0; t < my_tiles; ++t) {
         const int tile = lid + t * G;
-        const int a_base = (tile / ntn) * 256 * K * 2, w_base = (tile % ntn) * 256 * K * 2;
+        const int a_base = (tile / ntn) * 256 * pitch, w_base = (tile % ntn) * 256 * pitch;
         for (int ks = 0; ks < nk; ++ks) {
             char* sb = smem + stage * 32768;
             // mode 1 alternates the row halves of the tile between steps (128 rows x 128 B per operand per step)
-            const int half_rows = MODE == 1 ? (ks & 1) * 128 * K * 2 : 0;
+            const int half_rows = MODE == 1 ? (ks & 1) * 128 * pitch : 0;
             const int kof = MODE == 1 ? (ks >> 1) * 128 : ks * 64;   // mode 1: a pair of steps covers one 128-B column
             for (int i = 0; i < 4; ++i) {
                 const int piece = wave + 8 * i;
                 const bool isA = piece < 16;
                 const int so = (isA ? a_base : w_base) + half_rows + kof;
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(isA ? rsrcA : rsrcW, (lds_ptr_t)(sb + piece * 1024), 16, voff[i], so, 0, 0);
+                if (!NODMA) __builtin_amdgcn_raw_ptr_buffer_load_lds(isA ? rsrcA : rsrcW, (lds_ptr_t)(sb + piece * 1024), 16, voff[i], so, 0, 0);
                 if (MODE == 2) {                                  // the other half of the same lines, straight away
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(isA ? rsrcA : rsrcW, (lds_ptr_t)(smem + ((stage + 1) & 3) * 32768 + piece * 1024),
                                                              16, voff[i], so + 64, 0, 0);
                 }
             }
+            if (READS) {
+                const char* S = smem + ((stage + 2) & 3) * 32768;   // a stage that landed two steps ago
+#pragma unroll
+                for (int j = 0; j < 4; ++j) fb[j] = *reinterpret_cast<const f16x8*>(S + w_off + j * 256);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) fa[i] = *reinterpret_cast<const f16x8*>(S + a_off + i * 1024);
+            }
+            if (MFMA) {
+                const int rep = MODE == 2 ? 2 : 1;
+                for (int r = 0; r < rep; ++r) {
+#pragma unroll
+                    for (int i = 0; i < 32; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb[i & 3], fa[i >> 2], acc[i], 0, 0, 0);
+                }
+                if (!NODMA)
+                    for (int r = 0; r < (MODE == 2 ? 8 : 4); ++r) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                    }
+                if (READS) {
+                    for (int r = 0; r < 12; ++r) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    }
+                    __builtin_amdgcn_sched_group_barrier(0x008, 12, 0);
+                }
+            }
+            if (READS) __builtin_amdgcn_s_waitcnt(0xc07f);
             if (MODE == 2) { ++ks; wait_vm<8>(); } else { wait_vm<4>(); }
             __builtin_amdgcn_s_barrier();
             stage = (stage + (MODE == 2 ? 2 : 1)) & 3;
@@ -64,29 +108,31 @@ __global__ __launch_bounds__(512, 1) void probe(const _Float16* A, const _Float1
     }
     wait_vm<0>();
     __builtin_amdgcn_s_barrier();
-    if (sink && tid == 0) sink[blockIdx.x] = reinterpret_cast<float*>(smem)[lane];
+    float sacc = 0.f;
+    if (MFMA) for (int i = 0; i < 32; ++i) sacc += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+    if (sink && (tid == 0 || sacc == 12345.678f)) sink[blockIdx.x] = reinterpret_cast<float*>(smem)[lane] + sacc;
 #endif
 }
 
-template <int MODE>
-static void run(const char* name, const _Float16* A, const _Float16* W, float* sink) {
+template <int MODE, bool MFMA = false, bool READS = false, bool NODMA = false>
+static void run(const char* name, const _Float16* A, const _Float16* W, float* sink, int pitch = 2048) {
     const int M = 66688, N = 1024, K = 1024, ntn = N / 256, ntiles = ((M + 255) / 256) * ntn;
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&probe<MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&probe<MODE, MFMA, READS, NODMA>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    hipLaunchKernelGGL((probe<MODE>), dim3(256), dim3(512), 131072, 0, A, W, M, N, K, ntn, ntiles, sink);
+    hipLaunchKernelGGL((probe<MODE, MFMA, READS, NODMA>), dim3(256), dim3(512), 131072, 0, A, W, M, N, K, ntn, ntiles, sink, pitch);
     hipEventRecord(e0, 0);
     const int reps = 5;
-    for (int r = 0; r < reps; ++r) hipLaunchKernelGGL((probe<MODE>), dim3(256), dim3(512), 131072, 0, A, W, M, N, K, ntn, ntiles, sink);
+    for (int r = 0; r < reps; ++r) hipLaunchKernelGGL((probe<MODE, MFMA, READS, NODMA>), dim3(256), dim3(512), 131072, 0, A, W, M, N, K, ntn, ntiles, sink, pitch);
     hipEventRecord(e1, 0); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
     const double us = ms * 1e3 / reps;
     const double bytes = (double)ntiles * (K / 32) * 32768.0;       // same bytes in every mode
-    printf("%-46s %8.1f us per launch  %.2f TB/s chip-wide  %.1f GB/s per CU  (%s)\n", name, us, bytes / us / 1e6, bytes / us / 1e3 / 256,
+    printf("%-46s pitch %4d B %8.1f us per launch  %.2f TB/s chip-wide  %.1f GB/s per CU  (%s)\n", name, pitch, us, bytes / us / 1e6, bytes / us / 1e3 / 256,
            hipGetErrorString(hipGetLastError()));
 }
 
 int main() {
-    const size_t an = (size_t)(66688 + 256) * 1024, wn = (size_t)1024 * 1024;
+    const size_t an = (size_t)(66688 + 256) * 1280, wn = (size_t)1024 * 1280;      // room for padded row pitches
     _Float16 *A, *W; float* sink;
     hipMalloc(&A, an * 2); hipMalloc(&W, wn * 2); hipMalloc(&sink, 4096);
     hipMemset(A, 0x3c, an * 2); hipMemset(W, 0x3c, wn * 2);
@@ -94,5 +140,19 @@ int main() {
     run<1>("128 B per row per piece (K slab 64)", A, W, sink);
     run<2>("64 B halves of a line back to back (slab pair)", A, W, sink);
     run<0>("64 B per row per piece (K slab 32), again", A, W, sink);
+    run<0, true>("64 B pieces + 32 MFMA per wave and step", A, W, sink);
+    run<1, true>("128 B pieces + 32 MFMA per wave and step", A, W, sink);
+    run<2, true>("64 B line pairs + 64 MFMA per pair of steps", A, W, sink);
+    run<0, true>("64 B pieces + 32 MFMA per wave and step, again", A, W, sink);
+    run<0, true, false, true>("32 MFMA per wave and step only", A, W, sink);
+    run<0, true, true, true>("32 MFMA + 12 fragment reads, no staging", A, W, sink);
+    run<0, true, true, false>("32 MFMA + 12 fragment reads + 64 B pieces", A, W, sink);
+    run<1, true, true, false>("32 MFMA + 12 fragment reads + 128 B pieces", A, W, sink);
+    run<0, true, true, true>("32 MFMA + 12 fragment reads, no staging, again", A, W, sink);
+    // L2 channel spread: the operands' rows are 2 KiB apart (K = 1 024 halves); pad the row pitch
+    for (int pitch : {2048 + 64, 2048 + 128, 2048 + 256, 2048 + 512}) {
+        run<0>("64 B per row per piece", A, W, sink, pitch);
+        run<1>("128 B per row per piece", A, W, sink, pitch);
+    }
     return 0;
 }
