@@ -1159,8 +1159,8 @@ extern "C" int gdx_bench_gemm_f16(int32_t M, int32_t N, int32_t K, int32_t gelu,
             g2_dbg_buf = dd;
             (void)launch_gemmh(p, s);
             g2_dbg_buf = nullptr;
-            unsigned long long hh[16] = {0};
-            (void)hipMemcpyAsync(hh, dd, 128, hipMemcpyDeviceToHost, s);
+            unsigned long long hh[48] = {0};
+            (void)hipMemcpyAsync(hh, dd, 384, hipMemcpyDeviceToHost, s);
             (void)hipStreamSynchronize(s);
             if (hh[12] && hh[11])
                 fprintf(stderr, "[gemmh8 stamps] block 0, wave 0: %llu tiles, loop %.1f us at %.2f GHz; per tile: drain before the stores %.0f cycles, "

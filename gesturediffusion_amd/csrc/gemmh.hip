@@ -915,39 +915,90 @@ bool gemmh_supported(const GemmHParams& p) {
            (!p.R || p.ldr % 4 == 0) && (!p.V || p.ldv % 4 == 0);
 }
 
+// Tile choice for an M x N x K problem: the cheapest of the 4 + 4-wave shapes and the 256 x 256 eight-wave kernel (mb == 16).
+struct GhChoice { double cost; int tmb, tnbw; };
+static GhChoice gh_choose(const GemmHParams& p, int M, int num_cus, int force_mb, int force_nbw) {
+    GhChoice c{1e30, 0, 0};
+#define X(mb, nbw, nst)                                                           \
+    if (gh_valid(mb, nbw, nst, p)) {                                              \
+        double e = gh_cost(mb, nbw, M, p.N, p.K, num_cus, p.gelu != 0);           \
+        if (force_mb == mb && force_nbw == nbw) e = 0.0;                          \
+        if (e < c.cost) c = GhChoice{e, mb, nbw};                                 \
+    }
+    GH_CONFIGS(X)
+#undef X
+    const bool ok8 = p.K >= 128 && p.N % 256 == 0 && (size_t)4 * 32768 + (size_t)p.N * 4 <= 160 * 1024;
+    if (ok8) {
+        const double e = force_mb == 16 ? 0.0 : gh_cost(16, 4, M, p.N, p.K, num_cus, p.gelu != 0);
+        if ((force_mb == 16 || !force_mb) && e < c.cost) c = GhChoice{e, 16, 4};
+    }
+    return c;
+}
+
+static hipError_t launch_gh_choice(const GemmHParams& p, const GhChoice& c, int num_cus, hipStream_t s) {
+    if (c.tmb == 16) {
+        static const bool lines = getenv("GDX_GEMMH8_HALFLINES") == nullptr;   // A/B switch: the 64-byte-row ring
+        if (lines && p.K >= 256) return launch_cfg_h8b(p, num_cus, s);
+        return launch_cfg_h8(p, num_cus, s);
+    }
+#define X(mb, nbw, nst) \
+    if (c.tmb == mb && c.tnbw == nbw) return launch_cfg_h<mb, nbw, nst>(p, num_cus, s);
+    GH_CONFIGS(X)
+#undef X
+    return hipErrorInvalidValue;
+}
+
 hipError_t launch_gemmh(const GemmHParams& p, hipStream_t s) {
     if (!gemmh_supported(p)) return hipErrorInvalidValue;
     const int num_cus = gemm2_num_cus();
-    int best_mb = 0, best_nbw = 0;
     static int force_mb = -1, force_nbw = -1;
     if (force_mb < 0) {
         force_mb = force_nbw = 0;
         if (const char* e = getenv("GDX_GEMMH_TILE")) sscanf(e, "%d,%d", &force_mb, &force_nbw);
     }
     static const bool debug = getenv("GDX_GEMM_DEBUG") != nullptr;
-    double best = 1e30;
-#define X(mb, nbw, nst)                                                           \
-    if (gh_valid(mb, nbw, nst, p)) {                                              \
-        double c = gh_cost(mb, nbw, p.M, p.N, p.K, num_cus, p.gelu != 0);         \
-        if (force_mb == mb && force_nbw == nbw) c = 0.0;                          \
-        if (c < best) { best = c; best_mb = mb; best_nbw = nbw; }                 \
+    static const bool no_split = getenv("GDX_GEMMH_NOSPLIT") != nullptr;      // A/B switch
+    const bool gelu = p.gelu != 0;
+    const GhChoice whole = gh_choose(p, p.M, num_cus, force_mb, force_nbw);
+    if (!whole.tmb) return hipErrorNotSupported;
+    // Row cut.  With 256 x 256 tiles the tile count is rarely a multiple of the CU count: config 5's M = 66 688 rows are
+    // 261 row tiles, x 4 column tiles = 1 044 tiles = 4.08 rounds on 256 CUs, and the persistent kernel then runs FIVE
+    // rounds with the last one 8 % full.  So the rows are cut at the last whole round: the first `main` rows (a whole
+    // number of rounds of 256 x 256 tiles) go to the eight-wave kernel and the remaining rows to whichever shape the cost
+    // model picks for them, as a second launch on the same stream (measured, 200 launches back to back, N = K = 1 024:
+    // 159.3 -> 151.4 us; N = 3 072: unchanged, 420 us -- profiles/r02e_fp16_gemm_bound.txt).  Every output element is
+    // still one k-ascending sum (see the headers), so the cut does not change a single bit.  It needs the plain row-major
+    // epilogue (no token-row map, no per-sample vector: those index by the absolute row).
+    if (whole.tmb == 16 && !no_split && !force_mb && !p.rowmap && !p.V) {
+        const int ntn = p.N / 256, ntm = (p.M + 255) / 256;
+        const long tiles = (long)ntm * ntn, full = tiles / num_cus;
+        const int m_main = (int)(full * num_cus / ntn) * 256;
+        if (full >= 1 && tiles % num_cus != 0 && m_main > 0 && m_main < p.M && (long)m_main * p.lda * 2 < (long)p.a_bytes) {
+            GemmHParams pm = p, pt = p;
+            pm.M = m_main;
+            pm.a_bytes = (int)((long)m_main * p.lda * 2);
+            pt.M = p.M - m_main;
+            pt.A = p.A + (long)m_main * p.lda;
+            pt.a_bytes = p.a_bytes - pm.a_bytes;
+            if (p.R) pt.R = p.R + (long)m_main * p.ldr;
+            if (p.C32) pt.C32 = p.C32 + (long)m_main * p.ldc32;
+            if (p.C16) pt.C16 = p.C16 + (long)m_main * p.ldc16;
+            const GhChoice tail = gh_choose(pt, pt.M, num_cus, 0, 0);
+            // a last round that is nearly empty runs faster than a full one (fewer CUs stream): price it at half a round
+            const double c_main = gh_cost(16, 4, m_main, p.N, p.K, num_cus, gelu);
+            const double c_whole = c_main + 0.5 * (whole.cost - c_main);
+            if (tail.tmb && c_main + tail.cost + 2.0 < c_whole) {
+                if (debug)
+                    fprintf(stderr, "[gemmh] M=%d N=%d K=%d -> rows 0..%d as 256x256 tiles (%ld rounds), %d rows as %dx%d tiles\n",
+                            p.M, p.N, p.K, m_main, full, pt.M, tail.tmb * 16, tail.tnbw * 64);
+                hipError_t e = launch_gh_choice(pm, GhChoice{c_main, 16, 4}, num_cus, s);
+                if (e != hipSuccess) return e;
+                return launch_gh_choice(pt, tail, num_cus, s);
+            }
+        }
     }
-    GH_CONFIGS(X)
-#undef X
-    const bool ok8 = p.K >= 128 && p.N % 256 == 0 && (size_t)4 * 32768 + (size_t)p.N * 4 <= 160 * 1024;
-    if (ok8 && (force_mb == 16 || (!force_mb && gh_cost(16, 4, p.M, p.N, p.K, num_cus, p.gelu != 0) < best))) {
-        if (debug) fprintf(stderr, "[gemmh] M=%d N=%d K=%d -> tile 256x256 (8 MFMA waves)\n", p.M, p.N, p.K);
-        static const bool lines = getenv("GDX_GEMMH8_HALFLINES") == nullptr;   // A/B switch: the 64-byte-row ring above
-        if (lines && p.K >= 256) return launch_cfg_h8b(p, num_cus, s);
-        return launch_cfg_h8(p, num_cus, s);
-    }
-    if (!best_mb) return hipErrorNotSupported;
-    if (debug) fprintf(stderr, "[gemmh] M=%d N=%d K=%d -> tile %dx%d\n", p.M, p.N, p.K, best_mb * 16, best_nbw * 64);
-#define X(mb, nbw, nst) \
-    if (best_mb == mb && best_nbw == nbw) return launch_cfg_h<mb, nbw, nst>(p, num_cus, s);
-    GH_CONFIGS(X)
-#undef X
-    return hipErrorInvalidValue;
+    if (debug) fprintf(stderr, "[gemmh] M=%d N=%d K=%d -> tile %dx%d\n", p.M, p.N, p.K, whole.tmb * 16, whole.tnbw * 64);
+    return launch_gh_choice(p, whole, num_cus, s);
 }
 
 }  // namespace gdx

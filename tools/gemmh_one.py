@@ -9,7 +9,7 @@ lib = _lib.load(); torch.cuda.init()
 s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
 M, N, K, gelu = (int(a) for a in sys.argv[1:5]); iters = int(sys.argv[5]) if len(sys.argv) > 5 else 20
 if os.environ.get("CHECK", "1") == "1":
-    Mc = min(M, 1000)
+    Mc = min(M, int(os.environ.get("CHECK_M", "1000")))
     g = torch.Generator(device="cuda").manual_seed(1)
     A = torch.randn(Mc, K, device="cuda", generator=g); W = torch.randn(N, K, device="cuda", generator=g) / K ** 0.5
     b = torch.randn(N, device="cuda", generator=g)
