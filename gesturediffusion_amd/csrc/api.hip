@@ -355,6 +355,172 @@ extern "C" int gdx_weights_ready(gdx_handle_t h) {
     return 0;
 }
 
+// ---- packed-weight image (the weight pre-packing cache) ----------------------------------------------
+// Everything gdx_set_weight builds -- the zero-padded K-contiguous fp32 panels, their fp16 twins in the fp16 mode, padded
+// bias vectors, LayerNorm vectors, the positional / rotary tables -- as ONE host blob: a header (magic, the gdx_config_t
+// it was built for, record count) and one {id, dims, byte count, bytes} record per device buffer in a fixed walk order.
+// A blob only loads into a handle created with the same configuration; its records are checked against the sizes the
+// handle computes itself, so a stale or foreign file is rejected instead of producing a wrong model.
+namespace {
+struct PackRec { int32_t id, n, k, npad, kpad, npad16, kpad16, pad; int64_t bytes; };
+struct PackHdr { char magic[8]; gdx_config_t cfg; int32_t nrec, pad; };
+const char PACK_MAGIC[8] = {'G', 'D', 'X', 'P', 'A', 'C', 'K', '2'};
+struct PackBuf { void** ptr; size_t bytes; PackRec rec; };
+}  // namespace
+
+// the walk: every device weight buffer of the handle with the size it has (export) or must have (import; dims from the config)
+static void pack_walk(gdx_model* h, std::vector<PackBuf>& out) {
+    const int d = h->d, J = h->J, ff = h->ff, mf = h->cfg.mfcc_dim;
+    int id = 0;
+    auto linear = [&](Packed& P, int n, int k, bool bias) {
+        PackRec r{};
+        r.n = n; r.k = k; r.npad = round_up(n, 128); r.kpad = round_up(k, 32);
+        r.npad16 = h->f16 ? round_up(n, 256) : 0; r.kpad16 = h->f16 ? round_up(k, 64) : 0;
+        r.id = id++; r.bytes = (int64_t)sizeof(float) * r.npad * r.kpad;
+        out.push_back({(void**)&P.w, (size_t)r.bytes, r});
+        r.id = id++; r.bytes = bias ? (int64_t)sizeof(float) * round_up(n, 128) : 0;
+        out.push_back({(void**)&P.bias, (size_t)r.bytes, r});
+        r.id = id++; r.bytes = h->f16 ? (int64_t)2 * r.npad16 * r.kpad16 : 0;
+        out.push_back({(void**)&P.w16, (size_t)r.bytes, r});
+    };
+    auto vec = [&](float** p, long n) {
+        PackRec r{};
+        r.id = id++; r.n = (int32_t)n; r.bytes = (int64_t)sizeof(float) * n;
+        out.push_back({(void**)p, (size_t)r.bytes, r});
+    };
+    const bool v2 = h->cfg.arch == GDX_ARCH_MDM;
+    linear(h->time0, d, d, true);
+    linear(h->time2, d, d, true);
+    linear(h->seed, d, J * h->cfg.seed_poses, true);
+    linear(h->in_x, d, J, true);
+    if (!v2) linear(h->in_mfcc, d, mf, false);
+    if (v2) {
+        linear(h->proj_pose, d, d, true);
+        linear(h->proj_audio, d, mf, false);
+        linear(h->proj_coa, d, d, false);
+    }
+    linear(h->outp, J, d, true);
+    for (Layer& ly : h->layers) {
+        linear(ly.qkv, 3 * d, d, true);
+        linear(ly.out, d, d, true);
+        linear(ly.ff1, ff, d, true);
+        linear(ly.ff2, d, ff, true);
+        vec(&ly.g1, d); vec(&ly.b1, d); vec(&ly.g2, d); vec(&ly.b2, d);
+    }
+    vec(&h->pe, (long)h->pe_rows * d);
+    if (v2) {
+        const int half = d / h->cfg.cl_head / 2;
+        vec(&h->rope_cos, (long)h->rope_rows * half);
+        vec(&h->rope_sin, (long)h->rope_rows * half);
+    }
+}
+
+extern "C" int gdx_packed_bytes(gdx_handle_t h, int64_t* bytes) {
+    if (!h || !bytes) return fail("gdx_packed_bytes: null argument");
+    if (gdx_weights_ready(h)) return -1;
+    std::vector<PackBuf> bufs;
+    pack_walk(h, bufs);
+    int64_t total = sizeof(PackHdr) + 3 * sizeof(int32_t) + sizeof(int32_t);     // header + pe_rows, rope_rows, f16, pad
+    for (const PackBuf& b : bufs) total += sizeof(PackRec) + (int64_t)((b.bytes + 15) / 16 * 16);
+    *bytes = total;
+    return 0;
+}
+
+extern "C" int gdx_export_packed(gdx_handle_t h, void* host, int64_t bytes, void* stream) {
+    if (!h || !host) return fail("gdx_export_packed: null argument");
+    int64_t need = 0;
+    if (gdx_packed_bytes(h, &need)) return -1;
+    if (bytes != need) return fail("gdx_export_packed: buffer size does not match gdx_packed_bytes");
+    hipStream_t s = (hipStream_t)stream;
+    std::vector<PackBuf> bufs;
+    pack_walk(h, bufs);
+    char* p = (char*)host;
+    PackHdr hd{};
+    memcpy(hd.magic, PACK_MAGIC, 8);
+    hd.cfg = h->cfg; hd.nrec = (int32_t)bufs.size();
+    memcpy(p, &hd, sizeof(hd)); p += sizeof(hd);
+    const int32_t extra[4] = {h->pe_rows, h->rope_rows, h->f16 ? 1 : 0, 0};
+    memcpy(p, extra, sizeof(extra)); p += sizeof(extra);
+    for (const PackBuf& b : bufs) {
+        memcpy(p, &b.rec, sizeof(PackRec)); p += sizeof(PackRec);
+        if (b.bytes) {
+            if (!*b.ptr) return fail("gdx_export_packed: a weight buffer is missing");
+            HIPCHK(hipMemcpyAsync(p, *b.ptr, b.bytes, hipMemcpyDeviceToHost, s));
+        }
+        p += (b.bytes + 15) / 16 * 16;
+    }
+    HIPCHK(hipStreamSynchronize(s));
+    return 0;
+}
+
+extern "C" int gdx_import_packed(gdx_handle_t h, const void* host, int64_t bytes, void* stream) {
+    if (!h || !host) return fail("gdx_import_packed: null argument");
+    if (bytes < (int64_t)(sizeof(PackHdr) + 16)) return fail("gdx_import_packed: blob too small");
+    const char* p = (const char*)host;
+    const char* end = p + bytes;
+    PackHdr hd;
+    memcpy(&hd, p, sizeof(hd)); p += sizeof(hd);
+    if (memcmp(hd.magic, PACK_MAGIC, 8)) return fail("gdx_import_packed: not a packed-weight image (bad magic)");
+    if (memcmp(&hd.cfg, &h->cfg, sizeof(gdx_config_t))) return fail("gdx_import_packed: image was built for another configuration");
+    int32_t extra[4];
+    memcpy(extra, p, sizeof(extra)); p += sizeof(extra);
+    if ((extra[2] != 0) != h->f16) return fail("gdx_import_packed: image was built for another compute dtype");
+    const int rope_need = h->cfg.arch == GDX_ARCH_MDM ? 1 : 0;
+    if (extra[0] <= 0 || extra[0] > (1 << 20) || extra[1] < rope_need || extra[1] > (1 << 20))
+        return fail("gdx_import_packed: implausible table sizes");
+    const int old_pe = h->pe_rows, old_rope = h->rope_rows;
+    h->pe_rows = extra[0]; h->rope_rows = extra[1];               // the walk sizes the tables from these
+    std::vector<PackBuf> bufs;
+    pack_walk(h, bufs);
+    // validate the whole blob before touching the handle
+    const char* why = nullptr;
+    const char* q = p;
+    if (hd.nrec != (int32_t)bufs.size()) why = "gdx_import_packed: record count mismatch";
+    for (size_t i = 0; !why && i < bufs.size(); ++i) {
+        const PackBuf& b = bufs[i];
+        if (q + sizeof(PackRec) > end) { why = "gdx_import_packed: truncated image"; break; }
+        PackRec r;
+        memcpy(&r, q, sizeof(r)); q += sizeof(PackRec);
+        if (memcmp(&r, &b.rec, sizeof(PackRec))) { why = "gdx_import_packed: record does not match this configuration"; break; }
+        q += (b.bytes + 15) / 16 * 16;
+        if (q > end) why = "gdx_import_packed: truncated image";
+    }
+    if (!why && q != end) why = "gdx_import_packed: trailing bytes";
+    if (why) {
+        h->pe_rows = old_pe; h->rope_rows = old_rope;
+        return fail(why);
+    }
+    // the tables may change size with the image: let them be re-allocated
+    if (h->pe_rows != old_pe) h->pe = nullptr;
+    if (h->rope_rows != old_rope) { h->rope_cos = nullptr; h->rope_sin = nullptr; }
+    hipStream_t s = (hipStream_t)stream;
+    for (PackBuf& b : bufs) {
+        p += sizeof(PackRec);
+        if (b.bytes) {
+            if (!*b.ptr && dev_alloc(h->allocs, b.ptr, b.bytes)) return -1;
+            HIPCHK(hipMemcpyAsync(*b.ptr, p, b.bytes, hipMemcpyHostToDevice, s));
+        }
+        p += (b.bytes + 15) / 16 * 16;
+    }
+    HIPCHK(hipStreamSynchronize(s));                             // the caller may free the host blob on return
+    // dims of the Packed structs (pack() sets them on the gdx_set_weight path)
+    auto dims = [&](Packed& P, int n, int k) {
+        P.n = n; P.k = k; P.npad = round_up(n, 128); P.kpad = round_up(k, 32);
+        if (h->f16) { P.npad16 = round_up(n, 256); P.kpad16 = round_up(k, 64); }
+    };
+    const int d = h->d, J = h->J, ff = h->ff, mf = h->cfg.mfcc_dim;
+    dims(h->time0, d, d); dims(h->time2, d, d); dims(h->seed, d, J * h->cfg.seed_poses); dims(h->in_x, d, J);
+    if (h->cfg.arch == GDX_ARCH_MDM) { dims(h->proj_pose, d, d); dims(h->proj_audio, d, mf); dims(h->proj_coa, d, d); }
+    else dims(h->in_mfcc, d, mf);
+    dims(h->outp, J, d);
+    for (Layer& ly : h->layers) { dims(ly.qkv, 3 * d, d); dims(ly.out, d, d); dims(ly.ff1, ff, d); dims(ly.ff2, d, ff); }
+    for (const auto& n : h->required) h->have.insert(n);
+    h->cond_set = false;
+    h->c2t_valid = false;
+    h->tables_valid = false;
+    return 0;
+}
+
 extern "C" int gdx_prepare(gdx_handle_t h, int32_t batch, int32_t frames) {
     if (!h) return fail("gdx_prepare: null handle");
     if (batch <= 0 || frames <= 0) return fail("gdx_prepare: batch and frames must be positive");

@@ -85,6 +85,23 @@ class Engine:
             self.set_weight(name, t)
         _lib.check(self.lib.gdx_weights_ready(self.handle), self.lib)
 
+    def export_packed(self, device):
+        """The handle's packed operand layout as one bytes object (gdx_export_packed)."""
+        n = C.c_int64()
+        _lib.check(self.lib.gdx_packed_bytes(self.handle, C.byref(n)), self.lib)
+        buf = (C.c_char * n.value)()
+        _lib.check(self.lib.gdx_export_packed(self.handle, buf, n.value, _stream(device)), self.lib)
+        return bytes(buf)
+
+    def import_packed(self, blob, device):
+        """Upload a blob written by export_packed; raises GdxError (handle untouched) if it was built for another
+        configuration, compute dtype or shape."""
+        if torch.device(device).type != "cuda":
+            raise GdxError(f"packed image target is {device}: the MI355X HIP path needs a device (no CPU fallback)")
+        _lib.check(self.lib.gdx_import_packed(self.handle, blob, len(blob), _stream(device)), self.lib)
+        self.device = device
+        self._cond_key = None
+
     # ------------------------------------------------------------------ shapes / conditioning
     def prepare(self, batch, frames):
         if self.shape != (batch, frames):

@@ -149,6 +149,13 @@ class _NativeDenoiser(nn.Module):
         named["sequence_pos_encoder.pe"] = self.sequence_pos_encoder.pe
         return named
 
+    def _new_engine(self, dtype):
+        eng = Engine(self._arch, self.input_feats, self.latent_dim, self.ff_size, self.num_layers, self.num_heads,
+                     self.seed_poses, cl_head=getattr(self, "cl_head", 8), window=10, compute_dtype=dtype)
+        self.__dict__["_eng"] = eng
+        self.__dict__["_eng_key"] = None
+        return eng
+
     def _get_engine(self, device):
         named = self._engine_tensors()
         key = tuple((k, v.data_ptr(), v._version) for k, v in named.items())
@@ -156,11 +163,11 @@ class _NativeDenoiser(nn.Module):
         dtype = getattr(self, "compute_dtype", None) or os.environ.get("GDX_COMPUTE_DTYPE", "fp32")
         if eng is not None and eng.compute_dtype != dtype:
             eng = None
+            self.__dict__["_packed_image"] = False
         if eng is None:
-            eng = Engine(self._arch, self.input_feats, self.latent_dim, self.ff_size, self.num_layers, self.num_heads,
-                         self.seed_poses, cl_head=getattr(self, "cl_head", 8), window=10, compute_dtype=dtype)
-            self.__dict__["_eng"] = eng
-            self.__dict__["_eng_key"] = None
+            eng = self._new_engine(dtype)
+        if self.__dict__.get("_packed_image"):
+            return eng                     # weights came from load_packed(): the module's own parameters are not the model
         if self.__dict__["_eng_key"] != key:
             for k, v in named.items():
                 if v.device != device:
@@ -173,6 +180,27 @@ class _NativeDenoiser(nn.Module):
 
     def _extra_engine_tensors(self, device):
         return {}
+
+    # ---- packed-weight image (include/gdx.h, gdx_export_packed / gdx_import_packed)
+    def export_packed(self, device):
+        """bytes: the kernels' operand layout of the CURRENT parameters (packs them first if needed)."""
+        return self._get_engine(torch.device(device)).export_packed(torch.device(device))
+
+    def load_packed(self, blob, device):
+        """Take the weights from a packed image instead of a state dict.  The module's nn.Parameters are left as they are
+        and are ignored from here on (state_dict() does NOT describe the loaded model); load_state_dict() or a change of
+        compute_dtype switches back to them.  Raises GdxError if the image was built for another configuration."""
+        dtype = getattr(self, "compute_dtype", None) or os.environ.get("GDX_COMPUTE_DTYPE", "fp32")
+        eng = self.__dict__.get("_eng")
+        if eng is None or eng.compute_dtype != dtype:
+            eng = self._new_engine(dtype)
+        eng.import_packed(blob, torch.device(device))
+        self.__dict__["_packed_image"] = True
+
+    def load_state_dict(self, *args, **kwargs):
+        self.__dict__["_packed_image"] = False
+        self.__dict__["_eng_key"] = None
+        return super().load_state_dict(*args, **kwargs)
 
     def _check_inputs(self, x, y):
         if y is None:

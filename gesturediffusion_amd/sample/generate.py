@@ -24,7 +24,7 @@ from ..model.cfg_sampler import ClassifierFreeSampleModel
 from ..utils import dist_util
 from ..utils.fixseed import fixseed
 from ..utils.init import init_state_dict, MFCC_DIM
-from ..utils.model_util import create_model_and_diffusion, load_checkpoint, load_model_wo_clip
+from ..utils.model_util import create_model_and_diffusion, load_checkpoint, load_model_cached, load_model_wo_clip
 from ..utils.parser_util import generate_args
 
 
@@ -84,7 +84,12 @@ def main(argv=None):
     args.mfcc_input = True if args.synthetic else args.mfcc_input
 
     model, diffusion = create_model_and_diffusion(args, None)
-    if args.model_path:
+    if args.model_path and args.packed_cache:
+        model.to(device)
+        how = load_model_cached(model, args.model_path, device, args.packed_cache)
+        if rank == 0:
+            print(f"### weights from the packed {how}" if how == "image" else "### weights from the checkpoint (packed image written)")
+    elif args.model_path:
         state_dict = load_checkpoint(args.model_path)
         load_model_wo_clip(model, state_dict)
     else:

@@ -22,6 +22,44 @@ def load_checkpoint(path):
     return torch.load(path, map_location="cpu", weights_only=True)
 
 
+def packed_image_path(cache_dir, checkpoint_path, model):
+    """File name of the packed-weight image of `checkpoint_path` for `model`'s architecture and compute dtype: keyed by the
+    checkpoint's content (sha256), so a re-trained file of the same name never matches a stale image."""
+    import hashlib
+    import os
+    h = hashlib.sha256()
+    with open(checkpoint_path, "rb") as f:
+        for block in iter(lambda: f.read(1 << 22), b""):
+            h.update(block)
+    dtype = getattr(model, "compute_dtype", None) or os.environ.get("GDX_COMPUTE_DTYPE", "fp32")
+    return os.path.join(cache_dir, f"{h.hexdigest()[:24]}-{type(model).__name__}-{dtype}.gdxpack")
+
+
+def load_model_cached(model, checkpoint_path, device, cache_dir):
+    """Checkpoint ingestion through the weight pre-packing cache.  First use of a checkpoint: the normal
+    path (`load_checkpoint` + `load_model_wo_clip`), then the packed operand layout is written to `cache_dir`.  Later uses:
+    the image is uploaded as it is -- no unpickling, no per-tensor repack; the module's nn.Parameters stay untouched
+    (`MDM.load_packed`).  Returns "image" or "checkpoint" (which path ran).  `model` must already be on `device`."""
+    import os
+    path = packed_image_path(cache_dir, checkpoint_path, model)
+    if os.path.exists(path):
+        with open(path, "rb") as f:
+            blob = f.read()
+        try:
+            model.load_packed(blob, device)
+            return "image"
+        except Exception as e:  # noqa: BLE001 - a stale / foreign / truncated image is not fatal: rebuild it
+            print(f"[packed cache] ignoring {path}: {e}")
+    load_model_wo_clip(model, load_checkpoint(checkpoint_path))
+    blob = model.export_packed(device)
+    os.makedirs(cache_dir, exist_ok=True)
+    tmp = path + f".tmp{os.getpid()}"
+    with open(tmp, "wb") as f:
+        f.write(blob)
+    os.replace(tmp, path)                                  # atomic: concurrent ranks never read a half-written image
+    return "checkpoint"
+
+
 def load_model_wo_clip(model, state_dict):
     """Non-strict load with the reference's two guarantees (`utils/model_util.py:6-9`, both AssertionError): the checkpoint
     holds no key the model does not know, and only CLIP weights may be absent from it."""

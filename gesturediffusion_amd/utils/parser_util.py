@@ -128,6 +128,9 @@ def add_native_options(parser):
     group.add_argument("--synthetic_audio", action='store_true',
                        help="With --synthetic: derive y['mfcc'] from synthetic audio through the GPU MFCC front end "
                             "(dataset.py:81-95) instead of drawing N(0,1) features.")
+    group.add_argument("--packed_cache", default='', type=str,
+                       help="Directory of packed-weight images: the first run of a checkpoint writes the kernels' operand "
+                            "layout there, later runs upload it instead of unpickling and repacking the checkpoint.")
     group.add_argument("--compute_dtype", default='fp32', choices=['fp32', 'fp16'],
                        help="fp32 = exact fp32 MFMA (reference precision); fp16 = fp16 MFMA operands, fp32 accumulate.")
 

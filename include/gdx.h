@@ -79,6 +79,21 @@ int gdx_set_weight(gdx_handle_t h, const char* name, const float* dev_ptr,
  * names in gdx_last_error(). */
 int gdx_weights_ready(gdx_handle_t h);
 
+/* ---- packed-weight image: the weight pre-packing cache -------------------- */
+/* The reference re-reads a checkpoint written by train/training_loop.py:265-285 through utils/model_util.py:6-9 on every
+ * start.  gdx_set_weight turns each tensor into the kernels' operand layout (zero-padded K-contiguous panels, their fp16
+ * twins in the fp16 mode, padded bias / LayerNorm vectors, positional and rotary tables); these three calls move that
+ * whole layout out of and into a handle as ONE host blob, so a caller can keep it next to the checkpoint and skip the
+ * per-tensor path.  The blob starts with a magic and the gdx_config_t it was built for; gdx_import_packed refuses
+ * (and leaves the handle untouched) unless the configuration, the compute dtype and every record's dimensions match
+ * what this handle computes for itself.  After a successful import gdx_weights_ready() holds.
+ *   gdx_packed_bytes : size of the blob for this handle (all weights must be set)
+ *   gdx_export_packed: fill `host` (exactly that many bytes); synchronises `stream`
+ *   gdx_import_packed: upload a blob; synchronises `stream` (the caller may free `host` on return) */
+int gdx_packed_bytes(gdx_handle_t h, int64_t* bytes);
+int gdx_export_packed(gdx_handle_t h, void* host, int64_t bytes, void* stream);
+int gdx_import_packed(gdx_handle_t h, const void* host, int64_t bytes, void* stream);
+
 /* ---- per-problem set-up ---------------------------------------------------------------- */
 /* Size the workspace for `batch` samples of `frames` frames (allocates; not capturable).
  * V2 requires frames % window == 0 (the reference's einops rearrange raises,

@@ -286,6 +286,100 @@ def test_checkpoint_roundtrip_vs_oracle(tmp_path):
     assert rel_err(got, torch.cat(want, dim=3)) < LOOP_TOL
 
 
+def _forward(m, cfg, B=3, T=20, compute_dtype=None):
+    from gesturediffusion_amd.utils.init import synthetic_inputs
+    x, seedp, mfcc = synthetic_inputs(cfg, B, T, seed=5)
+    t = torch.tensor([3, 500, 999][:B])
+    if compute_dtype is not None:
+        m.compute_dtype = compute_dtype
+    return m(x.to(dev()), t.to(dev()), y={"seed": seedp.to(dev()), "mfcc": mfcc.to(dev())}).clone()
+
+
+@pytest.mark.parametrize("arch", ["mdm", "mdm_old"])
+@pytest.mark.parametrize("dtype", ["fp32", "fp16"])
+def test_packed_image_roundtrip_is_bit_exact(arch, dtype):
+    """SURVEY 8f N2, the weight pre-packing cache: gdx_export_packed of a model with weights A, gdx_import_packed into a
+    model whose nn.Parameters hold different weights B -> that model computes exactly what A computes (every packed
+    panel, fp16 twin, bias / LayerNorm vector and table travelled); load_state_dict switches it back to its parameters."""
+    from gesturediffusion_amd.utils.init import init_state_dict
+    cfg = dict(TINY, arch=arch)
+    a = build_model(arch, cfg, init_state_dict(cfg, seed=31, perturb=True))
+    b = build_model(arch, cfg, init_state_dict(cfg, seed=32, perturb=True))
+    out_a, out_b = _forward(a, cfg, compute_dtype=dtype), _forward(b, cfg, compute_dtype=dtype)
+    assert not torch.equal(out_a, out_b)
+    blob = a.export_packed(dev())
+    assert blob[:8] == b"GDXPACK2" and len(blob) > 4 * sum(p.numel() for p in a.parameters())
+    b.load_packed(blob, dev())
+    assert torch.equal(_forward(b, cfg), out_a)                     # bit for bit
+    assert torch.equal(_forward(b, cfg, B=2, T=30), _forward(a, cfg, B=2, T=30))   # survives a re-prepare
+    b.load_state_dict(init_state_dict(cfg, seed=32, perturb=True), strict=False)
+    assert torch.equal(_forward(b, cfg), out_b)                     # back on its own parameters
+
+
+def test_packed_image_is_rejected_by_another_configuration():
+    from gesturediffusion_amd._lib import GdxError
+    from gesturediffusion_amd.utils.init import init_state_dict
+    cfg = dict(TINY, arch="mdm")
+    a = build_model("mdm", cfg, init_state_dict(cfg, seed=31, perturb=True))
+    blob = a.export_packed(dev())
+    other = dict(cfg, latent_dim=256)
+    c = build_model("mdm", other, init_state_dict(other, seed=33, perturb=True))
+    want = _forward(c, other)
+    with pytest.raises(GdxError, match="another configuration"):
+        c.load_packed(blob, dev())
+    f16 = build_model("mdm", cfg, init_state_dict(cfg, seed=34, perturb=True))
+    f16.compute_dtype = "fp16"
+    with pytest.raises(GdxError, match="another c"):                 # configuration (compute_dtype is part of gdx_config_t)
+        f16.load_packed(blob, dev())
+    d = build_model("mdm", cfg, init_state_dict(cfg, seed=35, perturb=True))
+    for bad, msg in ((blob[:-16], "truncated"), (b"NOTAPACK" + blob[8:], "bad magic"), (blob + b"\0" * 16, "trailing")):
+        with pytest.raises(GdxError, match=msg):
+            d.load_packed(bad, dev())
+    assert torch.equal(_forward(c, other), want)                     # a refused image leaves the handle as it was
+    d.load_packed(blob, dev())
+    assert torch.equal(_forward(d, cfg), _forward(a, cfg))
+
+
+def test_checkpoint_through_the_packed_cache(tmp_path):
+    """`sample.generate --model_path ... --packed_cache DIR` twice: the first run reads the checkpoint and writes the image,
+    the second uploads the image (the checkpoint file is not even opened for unpickling) and writes the same samples; a
+    checkpoint with different content under the same name gets a different image."""
+    from gesturediffusion_amd.sample import generate
+    from gesturediffusion_amd.utils import model_util
+    from gesturediffusion_amd.utils.init import init_state_dict
+    J, T, P = 37, 20, 10
+    cfg = dict(arch="mdm", njoints=J, nfeats=1, latent_dim=128, ff_size=1024, num_layers=2, num_heads=4, seed_poses=P)
+    run = tmp_path / "save" / "run"
+    run.mkdir(parents=True)
+    ckpt = run / "model000000001.pt"
+
+    def write(seed):
+        m = build_model("mdm", cfg, init_state_dict(cfg, seed=seed, perturb=True)).cpu()
+        torch.save({k: v for k, v in m.state_dict().items() if not k.startswith("clip_model.")}, ckpt)
+    write(41)
+    (run / "args.json").write_text(json.dumps(dict(dataset="humanml", num_frames=T, layers=2, latent_dim=128, cond_mask_prob=0.1,
+                                                   mfcc_input=True, seed_poses=P, noise_schedule="cosine", sigma_small=True)))
+    cache = tmp_path / "cache"
+    common = ["--model_path", str(ckpt), "--synthetic", "--synthetic_njoints", str(J), "--num_samples", "2", "--chunks", "1",
+              "--seed", "3", "--rng", "philox", "--timestep_respacing", "10", "--packed_cache", str(cache)]
+    outs = []
+    calls = []
+    real = model_util.load_checkpoint
+    model_util.load_checkpoint = lambda p: (calls.append(p), real(p))[1]
+    try:
+        for i in range(2):
+            assert generate.main(common + ["--output_dir", str(tmp_path / f"o{i}")]) == 0
+            outs.append(np.load(tmp_path / f"o{i}" / "results.npy", allow_pickle=True).item()["motion"])   # written just now
+        assert len(calls) == 1 and len(list(cache.glob("*.gdxpack"))) == 1      # second run: image only
+        assert np.array_equal(outs[0], outs[1])
+        write(42)                                                               # same name, new content
+        assert generate.main(common + ["--output_dir", str(tmp_path / "o2")]) == 0
+        assert len(calls) == 2 and len(list(cache.glob("*.gdxpack"))) == 2
+        assert not np.array_equal(np.load(tmp_path / "o2" / "results.npy", allow_pickle=True).item()["motion"], outs[0])
+    finally:
+        model_util.load_checkpoint = real
+
+
 # ------------------------------------------------------------------------------------------------ sharding
 def test_generate_two_ranks_equal_one_rank(tmp_path):
     """The CLI on 2 ranks (both on this GPU, gloo for the end-of-chunk gather) must write the samples 1 rank writes:

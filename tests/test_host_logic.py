@@ -294,3 +294,24 @@ def test_gg_collate_matches_reference_fixture():
     m2, c2 = ten.collate([None, {"inp": torch.ones(3, 1, 4)}, {"inp": torch.ones(3, 1, 2)}])
     assert m2.shape == (2, 3, 1, 4) and c2["y"]["lengths"].tolist() == [4, 2]
     assert c2["y"]["mask"][1, 0, 0].tolist() == [True, True, False, False]
+
+
+def test_packed_image_key_follows_checkpoint_content_arch_and_dtype(tmp_path):
+    """utils/model_util.packed_image_path: the image of a checkpoint is keyed by the file's content, the model class and the
+    compute dtype (no GPU needed for the key)."""
+    from gesturediffusion_amd.utils.model_util import packed_image_path
+
+    class MDM:
+        compute_dtype = None
+
+    class MDM_Old:
+        compute_dtype = "fp16"
+    a, b = tmp_path / "model000000001.pt", tmp_path / "copy.pt"
+    a.write_bytes(b"weights-1" * 1000)
+    b.write_bytes(b"weights-1" * 1000)
+    k = packed_image_path("cache", str(a), MDM())
+    assert k == packed_image_path("cache", str(b), MDM()) and k.endswith("-MDM-fp32.gdxpack")   # same content, other name
+    assert packed_image_path("cache", str(a), MDM_Old()).endswith("-MDM_Old-fp16.gdxpack")
+    a.write_bytes(b"weights-2" * 1000)
+    assert packed_image_path("cache", str(a), MDM()) != k                                       # same name, other content
+
