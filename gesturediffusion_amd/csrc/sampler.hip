@@ -166,6 +166,7 @@ __global__ void q_sample_kernel(const float* __restrict__ xs, const float* __res
 //   kind 0: eps_out = (c0*x - x0) / c1                                        (_predict_eps_from_xstart)
 //   kind 6: out = x0*c2 + c3*e0                                               (improved-Euler predictor)
 //   kind 7: out = c0*x - c1*(((c0*x - x0)/c1) - e1[t]*e0)                     (pred_xstart under condition_score; e0 = gradient)
+//   kind 8: out = c0*x - c1*x0                                                 (pred_xstart from an EPSILON / PREVIOUS_X output)
 //   kind 1..5: eps' = e0 | (3e0 - e1)/2 | (23e0 - 16e1 + 5e2)/12 | (55e0 - 59e1 + 37e2 - 9e3)/24 | (e0 + e1)/2
 //              pred' = c0*x - c1*eps';  out = (pred'*c2 + c3*eps')*nz + x0*(1 - nz)
 __global__ void plms_kernel(int kind, const float* __restrict__ coef, const int64_t* __restrict__ t, int step_index,
@@ -182,6 +183,10 @@ __global__ void plms_kernel(int kind, const float* __restrict__ coef, const int6
     }
     if (kind == 6) {
         out[i] = __fadd_rn(__fmul_rn(x0[i], c[2]), __fmul_rn(c[3], e0[i]));
+        return;
+    }
+    if (kind == 8) {   // c0*x - c1*x0: _predict_xstart_from_eps (x = x_t, x0 slot = eps) and, with the (1/coef1, coef2/coef1)
+        out[i] = __fsub_rn(__fmul_rn(c[0], x[i]), __fmul_rn(c[1], x0[i]));   // rows, _predict_xstart_from_xprev (x = xprev, slot = x_t)
         return;
     }
     if (kind == 7) {   // condition_score (:452-472): e0 = cond_fn gradient, e1[idx] = sqrt(1 - alpha_bar) table
@@ -371,9 +376,9 @@ extern "C" int gdx_masked_l2(const float* a, const float* b, const uint8_t* mask
 
 extern "C" int gdx_plms_update(const gdx_plms_args_t* a, void* stream) {
     if (!a || !a->coef || !a->out) return gdx_set_error_("gdx_plms_update: null argument");
-    if (a->kind < 0 || a->kind > 7) return gdx_set_error_("gdx_plms_update: bad kind");
+    if (a->kind < 0 || a->kind > 8) return gdx_set_error_("gdx_plms_update: bad kind");
     const int k = a->kind;
-    const bool need_x = k != 6, need_x0 = true, need_e0 = k != 0, need_e1 = k == 2 || k == 3 || k == 4 || k == 5 || k == 7,
+    const bool need_x = k != 6, need_x0 = true, need_e0 = k != 0 && k != 8, need_e1 = k == 2 || k == 3 || k == 4 || k == 5 || k == 7,
                need_e2 = k == 3 || k == 4, need_e3 = k == 4;
     if ((need_x && !a->x) || (need_x0 && !a->pred_xstart) || (need_e0 && !a->eps[0]) || (need_e1 && !a->eps[1]) ||
         (need_e2 && !a->eps[2]) || (need_e3 && !a->eps[3]))

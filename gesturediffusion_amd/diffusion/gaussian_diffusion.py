@@ -10,9 +10,11 @@ coefficient rows; every per-element operation runs in libgdx.so:
   * `gdx_sampler_update`  CFG blend + inpainting + posterior mean / DDIM step + noise, one pass
   * `gdx_sample_loop`     the whole loop enqueued from C++ with in-kernel Philox noise
 
-Supported configuration = the one the reference hard-codes (`utils/model_util.py:37-72`):
-START_X mean, FIXED_SMALL / FIXED_LARGE variance.  The backward half of training, cond_fn_with_grad and
-learned variances are outside the hot path and raise NotImplementedError.
+Configured mode = the one the reference hard-codes (`utils/model_util.py:37-72`): START_X mean, FIXED_SMALL / FIXED_LARGE
+variance; this is what `gdx_sample_loop` runs.  The other two readings of the denoiser output, EPSILON and PREVIOUS_X
+(`:357-372`), go through the step-wise protocol (one extra element-wise launch per step).  The backward half of training
+and cond_fn_with_grad (autograd through the denoiser) raise NotImplementedError, and so do learned variances: they need a
+denoiser with twice the channels, which neither MDM has (the reference's own assert at `:317` fires for them).
 
 RNG.  `rng="torch"` (default) draws x_T with `torch.randn` and one N(0,1) tensor per step from torch's
 generator on the sample's device, in the reference's order (`:694`, `:532`), so a run is reproducible against
@@ -131,9 +133,36 @@ class GaussianDiffusion:
         raise NotImplementedError("learned variances are outside the sampling hot path")
 
     def _check_supported(self):
-        if self.model_mean_type != ModelMeanType.START_X:
-            raise NotImplementedError("only ModelMeanType.START_X (the reference's configuration) is implemented")
+        """START_X (the reference's configuration; the only reading the fused loop takes), EPSILON and PREVIOUS_X
+        (step-wise protocol) with fixed variances.  Learned variances need a denoiser with 2x the channels, which neither
+        MDM nor MDM_Old has (the reference's own assert at :317 fires for them)."""
         self._model_variance_tables()
+
+    def _xstart_table(self, device):
+        """Rows (c0, c1) of gdx_plms_update kind 8 for the configured reading of the denoiser output, rounded like every
+        other table (fp64 -> .float()): EPSILON (sqrt_recip_alphas_cumprod, sqrt_recipm1_alphas_cumprod), reference
+        :390-396; PREVIOUS_X (1 / posterior_mean_coef1, posterior_mean_coef2 / posterior_mean_coef1), :398-405."""
+        key = ("xstart", self.model_mean_type, str(device))
+        if key not in self._coef_cache:
+            f32 = lambda a: th.from_numpy(np.ascontiguousarray(a, dtype=np.float64)).float()   # noqa: E731
+            c = th.zeros(self.num_timesteps, 8, dtype=th.float32)
+            if self.model_mean_type == ModelMeanType.EPSILON:
+                c[:, 0], c[:, 1] = f32(self.sqrt_recip_alphas_cumprod), f32(self.sqrt_recipm1_alphas_cumprod)
+            else:
+                c[:, 0] = f32(1.0 / self.posterior_mean_coef1)
+                c[:, 1] = f32(self.posterior_mean_coef2 / self.posterior_mean_coef1)
+            self._coef_cache[key] = c.to(device)
+        return self._coef_cache[key]
+
+    def _identity_mean_table(self, device):
+        """The ancestral coefficient rows with mean = 1 * x0-slot + 0 * x_t: PREVIOUS_X takes the denoiser output itself
+        as the posterior mean (:361), and 1 * m + 0 * x is m bit for bit."""
+        key = ("identity", str(device))
+        if key not in self._coef_cache:
+            c = self.coef_table(GDX_SAMPLER_P, device).clone()
+            c[:, 0], c[:, 1] = 1.0, 0.0
+            self._coef_cache[key] = c
+        return self._coef_cache[key]
 
     def coef_table(self, kind, device, eta=0.0):
         """[num_timesteps, 8] fp32 rows consumed by gdx_sampler_update.  Every entry is rounded
@@ -220,6 +249,16 @@ class GaussianDiffusion:
         x0 = E.f32c(model_output, "model output")
         xc = E.f32c(x, "x")
         tt = t.to(th.int64).contiguous()
+        mean_type = self.model_mean_type
+        raw = None
+        if mean_type != ModelMeanType.START_X:
+            # EPSILON / PREVIOUS_X (reference :357-372): the x0 prediction is an element-wise function of the output and x_t
+            # (gdx_plms_update kind 8); everything downstream (process_xstart, posterior mean, DDIM / PLMS) then sees x0
+            # exactly as it does for START_X.  The inpainting blend supports START_X only, as in the reference (:309).
+            assert mask is None, 'This feature supports only X_start pred for mow!'
+            raw = x0
+            x0 = (E.plms_update(8, self._xstart_table(x.device), tt, xc, raw) if mean_type == ModelMeanType.EPSILON
+                  else E.plms_update(8, self._xstart_table(x.device), tt, raw, xc))
         if denoised_fn is not None:
             # rare path (every reference caller passes denoised_fn=None): the reference applies the inpainting blend, then
             # denoised_fn, then the clamp (:307-311, :349-355).  The blend runs in the update kernel (its pred_xstart output,
@@ -247,6 +286,18 @@ class GaussianDiffusion:
             grad = E.f32c(self._call_cond_fn(cond_fn, x, t, model_kwargs), "cond_fn gradient")
             assert grad.shape == x.shape
             gcoef = self._cond_coef(x.device) if kind == GDX_SAMPLER_DDIM else None
+        if mean_type == ModelMeanType.PREVIOUS_X and kind == GDX_SAMPLER_P:
+            # the posterior mean IS the output (:361); pred_xstart is only reported (and clamped by the same kernel's
+            # pred_xstart output in a pass of its own, zero noise)
+            if clip_denoised:
+                E.sampler_update(kind, self.coef_table(kind, x.device, eta), xc, x0, th.empty_like(xc), t=tt,
+                                 noise=th.zeros_like(xc), pred_xstart=pred, clip_denoised=True)
+            else:
+                pred = x0
+            E.sampler_update(kind, self._identity_mean_table(x.device), xc, raw, out, t=tt, noise=E.f32c(noise, "noise"),
+                             const_noise=const_noise, pred_xstart=th.empty_like(xc), cond_grad=grad, cond_coef=gcoef,
+                             clip_denoised=False)
+            return {"sample": out, "pred_xstart": pred}
         E.sampler_update(kind, self.coef_table(kind, x.device, eta), xc, x0, out, t=tt,
                          inpaint_mask=mask.contiguous() if mask is not None else None,
                          inpaint_motion=E.f32c(motion, "inpainted_motion") if motion is not None else None,
@@ -313,7 +364,8 @@ class GaussianDiffusion:
             raise ValueError(f"rng must be 'torch' or 'philox', got {rng!r}")
         device, img, indices = self._prepare_loop(model, shape, noise, device, skip_timesteps, init_image, rng,
                                                   philox_seed, sample_offset, noise_tape)
-        fused = not every_step and _is_native(model) and denoised_fn is None and cond_fn is None
+        fused = (not every_step and _is_native(model) and denoised_fn is None and cond_fn is None
+                 and self.model_mean_type == ModelMeanType.START_X)
         if fused:
             yield from self._fused_loop(kind, model, img, indices, model_kwargs, eta, const_noise, rng, philox_seed,
                                         sample_offset, noise_tape, dump_steps, progress, clip_denoised)

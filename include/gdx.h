@@ -176,6 +176,9 @@ int gdx_sampler_update(const gdx_update_args_t* a, void* stream);
  *   kind 6: out = pred_xstart*c2 + c3*eps[0]                           (pseudo improved Euler predictor :1048)
  *   kind 7: out = pred_xstart under condition_score (:452-472): eps[0] = cond_fn gradient [B,J,1,T],
  *           eps[1] = device table sqrt(1 - alpha_bar)[num_steps]
+ *   kind 8: out = c0*x - c1*pred_xstart-slot: the x0 prediction of a denoiser whose output is read as EPSILON (x = x_t,
+ *           slot = the output, DDIM rows: _predict_xstart_from_eps :390-396) or as PREVIOUS_X (x = the output, slot = x_t,
+ *           rows c0 = 1/posterior_mean_coef1, c1 = posterior_mean_coef2/posterior_mean_coef1: _predict_xstart_from_xprev :398-405)
  *   kind 1..4: Adams-Bashforth of that order over eps[0] (newest) .. eps[3]   (:1060-1069)
  *   kind 5: eps' = (eps[0] + eps[1]) / 2                               (improved Euler corrector :1050)
  *   kinds 1..5 then: pred' = c0*x - c1*eps';  out = (pred'*c2 + c3*eps')*nz + pred_xstart*(1 - nz)   (:1051-1077) */

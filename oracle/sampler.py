@@ -1,6 +1,7 @@
 """Oracle: sampler arithmetic and loops, CPU fp32 (test infrastructure only).
 
-Restates, for the configured mode START_X + FIXED_SMALL (utils/model_util.py:37-72),
+Restates, for the configured mode START_X + FIXED_SMALL (utils/model_util.py:37-72) and, in `mean_type_step`, for the
+EPSILON / PREVIOUS_X readings of the denoiser output and FIXED_LARGE variance (p_mean_variance :316-372),
 reference `diffusion/gaussian_diffusion.py`:
   q_sample :233-251, q_posterior_mean_variance :253-275, p_mean_variance :277-388
   (incl. the inpainting blend :307-311), _predict_eps_from_xstart :407-411,
@@ -65,8 +66,41 @@ def process_xstart(x0, clip_denoised=False, denoised_fn=None):
     return x0
 
 
+def predict_xstart_from_xprev(tab, xprev, x, t):
+    """_predict_xstart_from_xprev :398-405 (tables divided in fp64, then gathered and rounded like every other)."""
+    return extract(1.0 / tab.posterior_mean_coef1, t) * xprev - extract(tab.posterior_mean_coef2 / tab.posterior_mean_coef1, t) * x
+
+
+def model_log_variance(tab, t, var_large=False):
+    """FIXED_SMALL / FIXED_LARGE rows of p_mean_variance (:332-352)."""
+    import numpy as np
+    if var_large:
+        return extract(np.log(np.append(tab.posterior_variance[1], tab.betas[1:])), t)
+    return extract(tab.posterior_log_variance_clipped, t)
+
+
+def mean_type_step(tab, out, x, t, noise, y, kind, mean_type, eta=0.0, var_large=False, clip_denoised=False,
+                   denoised_fn=None):
+    """One p_sample / ddim_sample step for a denoiser output read as START_X, EPSILON or PREVIOUS_X (p_mean_variance
+    :357-372).  The inpainting blend asserts START_X in the reference (:309)."""
+    if "inpainting_mask" in y and "inpainted_motion" in y:
+        assert mean_type == "start_x", 'This feature supports only X_start pred for mow!'
+        out = inpaint(out, y)
+    if mean_type == "previous_x":
+        x0 = process_xstart(predict_xstart_from_xprev(tab, out, x, t), clip_denoised, denoised_fn)
+        mean = out
+    else:
+        x0 = process_xstart(out if mean_type == "start_x" else predict_xstart(tab, out, x, t), clip_denoised, denoised_fn)
+        mean = extract(tab.posterior_mean_coef1, t) * x0 + extract(tab.posterior_mean_coef2, t) * x
+    if kind == "ddim":
+        return ddim_step(tab, x0, x, t, noise, eta), x0
+    nonzero = (t != 0).float().view(-1, 1, 1, 1)
+    return mean + nonzero * torch.exp(0.5 * model_log_variance(tab, t, var_large)) * noise, x0
+
+
 def sample_loop(model_fn, tab, tmap, shape, tape, y, kind="p", eta=0.0, skip_timesteps=0,
-                init_image=None, const_noise=False, dump_steps=None, clip_denoised=False, denoised_fn=None):
+                init_image=None, const_noise=False, dump_steps=None, clip_denoised=False, denoised_fn=None,
+                mean_type="start_x", var_large=False):
     """Drive `model_fn(x, mapped_t, y) -> x0` through the whole reverse process.
 
     tape: list/tensor of N+1 noise tensors, tape[0] = x_T, tape[1+k] = z of the k-th
@@ -85,6 +119,10 @@ def sample_loop(model_fn, tab, tmap, shape, tape, y, kind="p", eta=0.0, skip_tim
     dump = []
     for k, i in enumerate(indices):
         t = torch.tensor([i] * B)
+        if mean_type != "start_x" or var_large:
+            img, _ = mean_type_step(tab, model_fn(img, map_tensor[t], y), img, t, tape[1 + k], y, kind, mean_type, eta,
+                                    var_large, clip_denoised, denoised_fn)
+            continue
         x0 = process_xstart(inpaint(model_fn(img, map_tensor[t], y), y), clip_denoised, denoised_fn)
         z = tape[1 + k]
         if kind == "p":
@@ -145,7 +183,8 @@ def plms_step(x0_fn, tab, x, t, order, old_eps):
     return mean_pred * nonzero + x0 * (1 - nonzero), x0, old_eps
 
 
-def plms_loop(model_fn, tab, tmap, shape, x_T, y, order=2, skip_timesteps=0, init_image=None):
+def plms_loop(model_fn, tab, tmap, shape, x_T, y, order=2, skip_timesteps=0, init_image=None, mean_type="start_x",
+              clip_denoised=False):
     """plms_sample_loop_progressive :1121-1190 (deterministic given x_T)."""
     B = shape[0]
     img = x_T
@@ -156,6 +195,9 @@ def plms_loop(model_fn, tab, tmap, shape, x_T, y, order=2, skip_timesteps=0, ini
         img = q_sample(tab, init_image, torch.ones(B, dtype=torch.long) * indices[0], img)
     map_tensor = torch.tensor(tmap, dtype=torch.long)
     x0_fn = lambda x, t: inpaint(model_fn(x, map_tensor[t], y), y)   # noqa: E731
+    if mean_type != "start_x" or clip_denoised:                      # pred_xstart of p_mean_variance for the other readings
+        x0_fn = lambda x, t: mean_type_step(tab, model_fn(x, map_tensor[t], y), x, t, torch.zeros_like(x), y, "p",   # noqa: E731
+                                            mean_type, clip_denoised=clip_denoised)[1]
     old = None
     for i in indices:
         img, _, old = plms_step(x0_fn, tab, img, torch.tensor([i] * B), order, old)

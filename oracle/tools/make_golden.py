@@ -83,11 +83,11 @@ def build_ref_model(mods, cfg, sd, double=False):
     return m
 
 
-def make_diffusion(gd, rs, respacing, schedule="cosine", steps=1000):
+def make_diffusion(gd, rs, respacing, schedule="cosine", steps=1000, mean_type="START_X", var_type="FIXED_SMALL"):
     betas = gd.get_named_beta_schedule(schedule, steps, 1.0)
     return rs.SpacedDiffusion(
         use_timesteps=rs.space_timesteps(steps, respacing if respacing else [steps]), betas=betas,
-        model_mean_type=gd.ModelMeanType.START_X, model_var_type=gd.ModelVarType.FIXED_SMALL,
+        model_mean_type=getattr(gd.ModelMeanType, mean_type), model_var_type=getattr(gd.ModelVarType, var_type),
         loss_type=gd.LossType.MSE, rescale_timesteps=False)
 
 
@@ -333,6 +333,57 @@ def gen_clip_tiny(mods, out):
         np.savez_compressed(os.path.join(out, f"clip_{arch}_tiny.npz"), **d)
 
 
+def gen_meantypes_tiny(mods, out):
+    """The mean / variance parametrisations of p_mean_variance other than the configured START_X + FIXED_SMALL
+    (:316-372): the denoiser's output read as EPSILON (_predict_xstart_from_eps :390-396) or as PREVIOUS_X
+    (_predict_xstart_from_xprev :398-405, mean = the output itself), and FIXED_LARGE variance -- whole loops of the
+    reference on the tiny models, same inputs / noise tape as loops_{arch}_tiny.npz (outputs only)."""
+    ref_cfg, gd, rs = mods[2], mods[3], mods[4]
+    for arch in ("mdm", "mdm_old"):
+        cfg = tiny_cfg(arch)
+        sd = init_state_dict(cfg, seed=2, perturb=True)
+        B, T = 3, 20
+        _, seedp, mfcc = synthetic_inputs(cfg, B, T, seed=5)
+        m = build_ref_model(mods, cfg, sd)
+        cfgm = ref_cfg.ClassifierFreeSampleModel(m)
+        g = torch.Generator().manual_seed(1234)
+        shape = (B, cfg["njoints"], 1, T)
+        tape = torch.randn(22, *shape, generator=g)
+        torch.randn(*shape, generator=g)                      # (init_image of the loops fixture)
+        mask = torch.zeros(shape, dtype=torch.bool)
+        mask[..., :5] = True
+        mask[:, :4] = True
+        motion = torch.randn(*shape, generator=g)
+        scale = torch.tensor([2.5, 1.0, 0.0])
+        y = {"seed": seedp, "mfcc": mfcc}
+        yin = dict(y, inpainting_mask=mask, inpainted_motion=motion, scale=scale)
+        d = {}
+
+        def run(kind, respacing, model, yy, mean_type, var_type="FIXED_SMALL", **kw):
+            df = make_diffusion(gd, rs, respacing, mean_type=mean_type, var_type=var_type)
+            fn = {"p": df.p_sample_loop, "ddim": df.ddim_sample_loop, "plms": df.plms_sample_loop}[kind]
+            with TapeNoise(tape[1:]):
+                return fn(model, shape, noise=tape[0].clone(), model_kwargs={"y": yy}, progress=False, **kw).numpy()
+        for tag, mt in (("eps", "EPSILON"), ("prevx", "PREVIOUS_X")):
+            d[f"{tag}_p20"] = run("p", [20], m, y, mt, clip_denoised=False)
+            d[f"{tag}_p20_clip"] = run("p", [20], m, y, mt, clip_denoised=True)
+            d[f"{tag}_p20_clip_cfg"] = run("p", [20], cfgm, dict(y, scale=scale), mt, clip_denoised=True)
+            try:                                                  # the inpainting blend asserts START_X (:309)
+                run("p", [20], m, yin, mt, clip_denoised=True)
+                raise SystemExit("expected the reference to refuse inpainting with " + mt)
+            except AssertionError:
+                pass
+            d[f"{tag}_p20_large"] = run("p", [20], m, y, mt, var_type="FIXED_LARGE", clip_denoised=True)
+            d[f"{tag}_ddim10_clip"] = run("ddim", "ddim10", m, y, mt, clip_denoised=True)
+            d[f"{tag}_ddim10_eta05"] = run("ddim", "ddim10", m, y, mt, clip_denoised=True, eta=0.5)
+            d[f"{tag}_p20_dfn"] = run("p", [20], m, y, mt, clip_denoised=True, denoised_fn=denoised_fn_fixture)
+            d[f"{tag}_plms10_clip"] = run("plms", "ddim10", m, y, mt, clip_denoised=True, order=2)
+        d["startx_p20_large"] = run("p", [20], m, y, "START_X", var_type="FIXED_LARGE", clip_denoised=False)
+        for k, v in d.items():
+            assert np.isfinite(v).all(), (arch, k)
+        np.savez_compressed(os.path.join(out, f"meantypes_{arch}_tiny.npz"), **d)
+
+
 def cond_fn_fixture(x, t, **kwargs):
     """Deterministic stand-in for a classifier gradient (the reference has no classifier): smooth in x, depends on t."""
     return 0.05 * torch.sin(x) * (1.0 + t.view(-1, 1, 1, 1).float() / 1000.0)
@@ -557,12 +608,12 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--ref", default="/root/reference")
     ap.add_argument("--out", default=os.path.join(REPO, "tests", "golden"))
-    ap.add_argument("--only", default="", help="comma-separated subset: schedule,forward,loops,plms,losses,guided,clip,collate,chunks,real,negative,keys")
+    ap.add_argument("--only", default="", help="comma-separated subset: schedule,forward,loops,plms,losses,guided,clip,meantypes,collate,chunks,real,negative,keys")
     args = ap.parse_args()
     os.makedirs(args.out, exist_ok=True)
     torch.set_num_threads(8)
     mods = import_reference(args.ref)
-    gens = {"schedule": gen_schedule, "forward": gen_forward_tiny, "loops": gen_loops_tiny, "plms": gen_plms_tiny, "losses": gen_losses_tiny, "guided": gen_guided_tiny, "clip": gen_clip_tiny,
+    gens = {"schedule": gen_schedule, "forward": gen_forward_tiny, "loops": gen_loops_tiny, "plms": gen_plms_tiny, "losses": gen_losses_tiny, "guided": gen_guided_tiny, "clip": gen_clip_tiny, "meantypes": gen_meantypes_tiny,
             "collate": gen_collate, "chunks": gen_chunks_tiny, "real": gen_real_shapes, "negative": gen_negative, "keys": gen_state_dict_keys}
     for name in (args.only.split(",") if args.only else gens):
         gens[name](mods, args.out)

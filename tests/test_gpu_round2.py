@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import REPO, load_golden, rel_err
+from conftest import REPO, load_golden, rel_err, weights_from
 from test_gpu_parity import FWD_TOL, LOOP_TOL, TINY, _diffusion, _real_cfg, build_model, dev
 
 pytestmark = pytest.mark.gpu
@@ -241,6 +241,61 @@ def test_chunk_driver_vs_reference_golden(arch, dtype, tol):
                          guidance_param=CHUNKS["scale"], noise_tapes=[t.to(d) for t in tapes])
     for c, o in enumerate(outs):
         assert rel_err(o.cpu(), g[f"{arch}.chunk{c}"]) < tol, c
+
+
+# ------------------------------------------------------------------------------------------------ mean / variance types
+from test_oracle_golden import MEANTYPES, MEANTYPE_TOL, denoised_fn_fixture, meantype_case  # noqa: E402
+
+
+@pytest.mark.parametrize("arch", ["mdm", "mdm_old"])
+@pytest.mark.parametrize("name", MEANTYPES)
+def test_mean_and_variance_types_vs_reference_golden(arch, name):
+    """p_mean_variance's other parametrisations (reference gaussian_diffusion.py:316-372): the denoiser output read as
+    EPSILON or PREVIOUS_X, FIXED_LARGE variance -- whole loops (ancestral, DDIM, PLMS; clip_denoised, CFG, denoised_fn)
+    through the step-wise protocol against the reference's own outputs (tests/golden/meantypes_*_tiny.npz)."""
+    from gesturediffusion_amd.diffusion import gaussian_diffusion as gd
+    from gesturediffusion_amd.diffusion.respace import SpacedDiffusion, space_timesteps
+    from gesturediffusion_amd.model.cfg_sampler import ClassifierFreeSampleModel
+    g = load_golden(f"loops_{arch}_tiny.npz")
+    gm = load_golden(f"meantypes_{arch}_tiny.npz")
+    cfg = dict(TINY, arch=arch)
+    m = build_model(arch, cfg, weights_from(g))
+    mean_type, sampler, resp, kw, large = meantype_case(name)
+    df = SpacedDiffusion(use_timesteps=space_timesteps(1000, resp), betas=gd.get_named_beta_schedule("cosine", 1000),
+                         model_mean_type={"epsilon": gd.ModelMeanType.EPSILON, "previous_x": gd.ModelMeanType.PREVIOUS_X,
+                                          "start_x": gd.ModelMeanType.START_X}[mean_type],
+                         model_var_type=gd.ModelVarType.FIXED_LARGE if large else gd.ModelVarType.FIXED_SMALL,
+                         loss_type=gd.LossType.MSE)
+    tape = torch.from_numpy(g["tape"]).to(dev())
+    y = {"seed": torch.from_numpy(g["seed"]).to(dev()), "mfcc": torch.from_numpy(g["mfcc"]).to(dev())}
+    model = m
+    if "cfg" in name:
+        y["scale"] = torch.from_numpy(g["scale"]).to(dev())
+        model = ClassifierFreeSampleModel(m)
+    shape = tuple(tape[0].shape)
+    if sampler == "plms":
+        out = df.plms_sample_loop(model, shape, noise=tape[0].clone(), clip_denoised=kw["clip_denoised"], model_kwargs={"y": y},
+                                  order=2)
+    else:
+        fn = df.p_sample_loop if sampler == "p" else df.ddim_sample_loop
+        out = fn(model, shape, noise_tape=tape, model_kwargs={"y": y}, **kw)
+    assert rel_err(out.cpu(), gm[name]) < max(LOOP_TOL, MEANTYPE_TOL.get(name, 0.0)), name
+
+
+def test_inpainting_with_epsilon_raises_like_the_reference():
+    from gesturediffusion_amd.diffusion import gaussian_diffusion as gd
+    from gesturediffusion_amd.diffusion.respace import SpacedDiffusion, space_timesteps
+    g = load_golden("loops_mdm_tiny.npz")
+    m = build_model("mdm", dict(TINY, arch="mdm"), weights_from(g))
+    df = SpacedDiffusion(use_timesteps=space_timesteps(1000, [20]), betas=gd.get_named_beta_schedule("cosine", 1000),
+                         model_mean_type=gd.ModelMeanType.EPSILON, model_var_type=gd.ModelVarType.FIXED_SMALL,
+                         loss_type=gd.LossType.MSE)
+    tape = torch.from_numpy(g["tape"]).to(dev())
+    y = {"seed": torch.from_numpy(g["seed"]).to(dev()), "mfcc": torch.from_numpy(g["mfcc"]).to(dev()),
+         "inpainting_mask": torch.from_numpy(g["inpainting_mask"]).to(dev()),
+         "inpainted_motion": torch.from_numpy(g["inpainted_motion"]).to(dev())}
+    with pytest.raises(AssertionError):                      # gaussian_diffusion.py:309
+        df.p_sample_loop(m, tuple(tape[0].shape), noise_tape=tape, model_kwargs={"y": y})
 
 
 # ------------------------------------------------------------------------------------------------ N2: checkpoints

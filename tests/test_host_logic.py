@@ -170,8 +170,8 @@ def test_coef_tables_match_oracle_rounding():
 def test_unsupported_modes_raise():
     from gesturediffusion_amd.diffusion import gaussian_diffusion as gd
     df = gd.GaussianDiffusion(betas=gd.get_named_beta_schedule("linear", 1000), model_mean_type=gd.ModelMeanType.EPSILON,
-                              model_var_type=gd.ModelVarType.FIXED_SMALL, loss_type=gd.LossType.MSE)
-    with pytest.raises(NotImplementedError):
+                              model_var_type=gd.ModelVarType.LEARNED_RANGE, loss_type=gd.LossType.MSE)
+    with pytest.raises(NotImplementedError):       # learned variances: no 2x-channel denoiser exists on the path
         df.coef_table(0, "cpu")
     with pytest.raises(NotImplementedError):       # the forward half is implemented for the configured mode only
         gd.GaussianDiffusion(betas=gd.get_named_beta_schedule("cosine", 1000), model_mean_type=gd.ModelMeanType.START_X,

@@ -172,6 +172,62 @@ def test_clip_denoised_and_denoised_fn_loops(arch, name):
     assert rel_err(r, gc[name]) < 2e-5, name
 
 
+MEANTYPES = [f"{tag}_{c}" for tag in ("eps", "prevx") for c in ("p20", "p20_clip", "p20_clip_cfg", "p20_large", "ddim10_clip",
+                                                                  "ddim10_eta05", "p20_dfn", "plms10_clip")] + ["startx_p20_large"]
+
+
+def meantype_case(name):
+    """(mean_type, sampler, respacing, kwargs) of a meantypes_{arch}_tiny.npz case; shared with the GPU test."""
+    tag, rest = name.split("_", 1)
+    mean_type = {"eps": "epsilon", "prevx": "previous_x", "startx": "start_x"}[tag]
+    sampler = "plms" if "plms" in rest else "ddim" if "ddim" in rest else "p"
+    kw = {"clip_denoised": "clip" in rest or "large" in rest and tag != "startx" or "eta05" in rest or "dfn" in rest}
+    if "dfn" in rest:
+        kw["denoised_fn"] = denoised_fn_fixture
+    if "eta05" in rest:
+        kw["eta"] = 0.5
+    return mean_type, sampler, ([20] if sampler == "p" else "ddim10"), kw, "large" in rest
+
+
+# eps_p20 runs the EPSILON reading without the clamp on a random-weight denoiser: x0 = 1/sqrt(ab) x - sqrt(1/ab - 1) eps
+# reaches 7e4 and the loop amplifies fp32 rounding differences by that much
+MEANTYPE_TOL = {"eps_p20": 5e-3}
+
+
+@pytest.mark.parametrize("arch", ["mdm", "mdm_old"])
+@pytest.mark.parametrize("name", MEANTYPES)
+def test_mean_and_variance_types_loops(arch, name):
+    """p_mean_variance's other parametrisations (reference gaussian_diffusion.py:316-372): EPSILON, PREVIOUS_X, FIXED_LARGE."""
+    g = load_golden(f"loops_{arch}_tiny.npz")
+    gm = load_golden(f"meantypes_{arch}_tiny.npz")
+    p = weights_from(g)
+    cfg = dict(TINY, arch=arch)
+    tape = torch.from_numpy(g["tape"])
+    y = {"seed": torch.from_numpy(g["seed"]), "mfcc": torch.from_numpy(g["mfcc"])}
+    fn = lambda x, t, yy: omf.forward(p, cfg, x, t, yy)     # noqa: E731
+    if "cfg" in name:
+        y["scale"] = torch.from_numpy(g["scale"])
+        fn = lambda x, t, yy: omf.cfg_forward(p, cfg, x, t, yy)     # noqa: E731
+    mean_type, sampler, resp, kw, large = meantype_case(name)
+    tab, tmap = osch.make_tables("cosine", 1000, resp)
+    with torch.no_grad():
+        if sampler == "plms":
+            r = osamp.plms_loop(fn, tab, tmap, tape[0].shape, tape[0], y, order=2, mean_type=mean_type,
+                                clip_denoised=kw["clip_denoised"])
+        else:
+            r = osamp.sample_loop(fn, tab, tmap, tape[0].shape, tape, y, kind=sampler, mean_type=mean_type, var_large=large, **kw)
+    assert rel_err(r, gm[name]) < MEANTYPE_TOL.get(name, 2e-5), name
+
+
+def test_inpainting_needs_start_x_like_the_reference():
+    g = load_golden("loops_mdm_tiny.npz")
+    y = {"inpainting_mask": torch.from_numpy(g["inpainting_mask"]), "inpainted_motion": torch.from_numpy(g["inpainted_motion"])}
+    tab, _ = osch.make_tables("cosine", 1000, [20])
+    x = torch.from_numpy(g["tape"][0])
+    with pytest.raises(AssertionError):
+        osamp.mean_type_step(tab, x, x, torch.tensor([5, 5, 5]), x, y, "p", "epsilon")
+
+
 PLMS = {"plms10_o2": (2, {}), "plms10_o3": (3, {}), "plms10_o4_cfg": (4, {}), "plms10_o2_inpaint": (2, {}),
         "plms10_o2_init_skip": (2, {"skip_timesteps": 3})}
 
