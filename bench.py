@@ -171,7 +171,7 @@ def main():
     ap.add_argument("--cfg", action="store_true", help="ClassifierFreeSampleModel (cond+uncond double batch)")
     ap.add_argument("--sampler", default=None, choices=["p", "ddim"])
     ap.add_argument("--respacing", default=None)
-    ap.add_argument("--dtype", default=None, choices=["fp32", "fp16"])
+    ap.add_argument("--dtype", default=None, choices=["fp32", "fp16", "bf16"])
     ap.add_argument("--seam", default="philox", choices=["philox", "torch", "stepwise"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU work the cpu_baseline leg may spend")
@@ -285,7 +285,7 @@ def main():
         rows, d, ff = (2 if p["cfg"] else 1) * min(sub, B) * (T + 1), p["d"], 1024
         gemm_us, gemm_launches = eng.profile_end()
         gemm_flops = 2.0 * rows * d * ff
-        f16 = p["dtype"] == "fp16"
+        f16 = p["dtype"] in ("fp16", "bf16")
         traffic, traffic_src = None, None
         if os.path.exists(TRAFFIC_FILE) and not custom:
             ent = json.load(open(TRAFFIC_FILE)).get(args.config)     # PMC passes cannot run inside this process
@@ -301,7 +301,7 @@ def main():
             "metric": f"denoised motion frames/sec ({loop_name}{' + CFG' if p['cfg'] else ''}, B={total if p['global_batch'] else p['batch']}, T={T}, d={p['d']})",
             "value": round(frames_per_sec, 2), "unit": "frames/s", "n_gpus": world, "steps": steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
-            "scaling": p["scaling"], "vs_baseline": None, "dtype": "f16 (fp32 accumulate)" if f16 else "f32",
+            "scaling": p["scaling"], "vs_baseline": None, "dtype": ("bf16 (fp32 accumulate)" if p["dtype"] == "bf16" else "f16 (fp32 accumulate)") if f16 else "f32",
             "data": "synthetic",
             "config": {
                 "workload": f"{p['label']}{' with custom overrides' if custom else ''}: {topo} J={J} d={p['d']} ff=1024 L={p['L']} H=4, "

@@ -46,6 +46,20 @@ __global__ void pack_weight_f16_kernel(const float* __restrict__ src, int src_ld
     dst[i] = (r < n && c < k) ? (_Float16)src[(long)r * src_ld + col0 + c] : (_Float16)0.0f;
 }
 
+// the same with bf16 elements (GDX_DTYPE_BF16); the destination is passed as an opaque 16-bit pointer like every half buffer
+__global__ void pack_weight_bf16_kernel(const float* __restrict__ src, int src_ld, int col0, int n, int k,
+                                        _Float16* __restrict__ dst_, int npad, int kpad) {
+    __bf16* dst = reinterpret_cast<__bf16*>(dst_);
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)npad * kpad) return;
+    const int r = i / kpad, c = i % kpad;
+    dst[i] = (r < n && c < k) ? (__bf16)src[(long)r * src_ld + col0 + c] : (__bf16)0.0f;
+}
+
+// half-type dispatch: the reduced-precision kernels exist as gdx:: (fp16) and gdx::b16:: (bf16) builds of one source
+#define HFN(bf, fn, ...) ((bf) ? gdx::b16::fn(__VA_ARGS__) : gdx::h16::fn(__VA_ARGS__))
+static bool g_test_bf16 = false;    // gdx_set_test_half_dtype: element type of the stand-alone test / bench entry points
+
 struct Packed {          // a Linear weight [n][k] packed to [npad][kpad] (+ bias [npad])
     float* w = nullptr;
     float* bias = nullptr;
@@ -68,7 +82,8 @@ int gdx_sampler_update_state_(const gdx_update_args_t* a, const int* state, long
 struct gdx_model {
     gdx_config_t cfg;
     int d, J, ff, L, H;
-    bool f16 = false;                 // cfg.compute_dtype == GDX_DTYPE_F16: fp16 MFMA operands, fp32 accumulate
+    bool f16 = false;                 // reduced-precision mode (GDX_DTYPE_F16 or _BF16): 16-bit MFMA operands, fp32 accumulate
+    bool bf16 = false;                // ... with bf16 elements (the gdx::b16 kernels)
     _Float16 *xt16 = nullptr, *xa16 = nullptr, *xb16 = nullptr, *qkv16 = nullptr, *ctx16 = nullptr, *ffb16 = nullptr,
              *emb16 = nullptr, *xc16 = nullptr, *tmp16 = nullptr, *xseq16 = nullptr;
     std::set<std::string> have;
@@ -123,10 +138,10 @@ static int dev_alloc(std::vector<void*>& pool, void** p, size_t bytes) {
 }
 
 static int pack_f16_into(_Float16* dst, const float* src, int n, int src_ld, int col0, int k, int npad, int kpad,
-                         hipStream_t s) {
+                         hipStream_t s, bool bf = false) {
     const long total = (long)npad * kpad;
-    hipLaunchKernelGGL(pack_weight_f16_kernel, dim3((total + 255) / 256), dim3(256), 0, s, src, src_ld, col0, n, k, dst,
-                       npad, kpad);
+    hipLaunchKernelGGL(bf ? pack_weight_bf16_kernel : pack_weight_f16_kernel, dim3((total + 255) / 256), dim3(256), 0, s, src,
+                       src_ld, col0, n, k, dst, npad, kpad);
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -141,7 +156,7 @@ static int pack(gdx_model* h, Packed& P, const float* src, int n, int src_ld, in
     if (h->f16) {
         P.npad16 = round_up(n, 256); P.kpad16 = round_up(k, 64);
         if (!P.w16 && dev_alloc(h->allocs, (void**)&P.w16, 2 * (size_t)P.npad16 * P.kpad16)) return -1;
-        if (pack_f16_into(P.w16, src, n, src_ld, col0, k, P.npad16, P.kpad16, s)) return -1;
+        if (pack_f16_into(P.w16, src, n, src_ld, col0, k, P.npad16, P.kpad16, s, h->bf16)) return -1;
     }
     return 0;
 }
@@ -160,9 +175,10 @@ extern "C" const char* gdx_last_error(void) { return g_err.c_str(); }
 extern "C" int gdx_create(const gdx_config_t* cfg, gdx_handle_t* out) {
     if (!cfg || !out) return fail("gdx_create: null argument");
     if (cfg->arch != GDX_ARCH_MDM && cfg->arch != GDX_ARCH_MDM_OLD) return fail("gdx_create: unknown arch");
-    if (cfg->compute_dtype != GDX_DTYPE_F32 && cfg->compute_dtype != GDX_DTYPE_F16) return fail("gdx_create: unknown compute_dtype");
-    if (cfg->compute_dtype == GDX_DTYPE_F16 && (cfg->latent_dim % 64 || cfg->ff_size % 64))
-        return fail("gdx_create: fp16 mode needs latent_dim and ff_size to be multiples of 64");
+    if (cfg->compute_dtype != GDX_DTYPE_F32 && cfg->compute_dtype != GDX_DTYPE_F16 && cfg->compute_dtype != GDX_DTYPE_BF16)
+        return fail("gdx_create: unknown compute_dtype");
+    if (cfg->compute_dtype != GDX_DTYPE_F32 && (cfg->latent_dim % 64 || cfg->ff_size % 64))
+        return fail("gdx_create: the fp16 / bf16 modes need latent_dim and ff_size to be multiples of 64");
     if (cfg->latent_dim <= 0 || cfg->latent_dim % 32) return fail("gdx_create: latent_dim must be a multiple of 32");
     if (cfg->ff_size <= 0 || cfg->ff_size % 32) return fail("gdx_create: ff_size must be a multiple of 32");
     if (cfg->num_heads <= 0 || cfg->latent_dim % cfg->num_heads) return fail("gdx_create: latent_dim % num_heads != 0");
@@ -179,7 +195,8 @@ extern "C" int gdx_create(const gdx_config_t* cfg, gdx_handle_t* out) {
     if (e != hipSuccess) return fail(std::string("gemm_init: ") + hipGetErrorString(e));
     gdx_model* h = new gdx_model();
     h->cfg = *cfg;
-    h->f16 = cfg->compute_dtype == GDX_DTYPE_F16;
+    h->f16 = cfg->compute_dtype != GDX_DTYPE_F32;
+    h->bf16 = cfg->compute_dtype == GDX_DTYPE_BF16;
     h->d = cfg->latent_dim; h->J = cfg->njoints; h->ff = cfg->ff_size; h->L = cfg->num_layers; h->H = cfg->num_heads;
     h->layers.resize(h->L);
     auto& r = h->required;
@@ -439,7 +456,7 @@ extern "C" int gdx_export_packed(gdx_handle_t h, void* host, int64_t bytes, void
     memcpy(hd.magic, PACK_MAGIC, 8);
     hd.cfg = h->cfg; hd.nrec = (int32_t)bufs.size();
     memcpy(p, &hd, sizeof(hd)); p += sizeof(hd);
-    const int32_t extra[4] = {h->pe_rows, h->rope_rows, h->f16 ? 1 : 0, 0};
+    const int32_t extra[4] = {h->pe_rows, h->rope_rows, h->cfg.compute_dtype, 0};
     memcpy(p, extra, sizeof(extra)); p += sizeof(extra);
     for (const PackBuf& b : bufs) {
         memcpy(p, &b.rec, sizeof(PackRec)); p += sizeof(PackRec);
@@ -464,7 +481,7 @@ extern "C" int gdx_import_packed(gdx_handle_t h, const void* host, int64_t bytes
     if (memcmp(&hd.cfg, &h->cfg, sizeof(gdx_config_t))) return fail("gdx_import_packed: image was built for another configuration");
     int32_t extra[4];
     memcpy(extra, p, sizeof(extra)); p += sizeof(extra);
-    if ((extra[2] != 0) != h->f16) return fail("gdx_import_packed: image was built for another compute dtype");
+    if (extra[2] != h->cfg.compute_dtype) return fail("gdx_import_packed: image was built for another compute dtype");
     const int rope_need = h->cfg.arch == GDX_ARCH_MDM ? 1 : 0;
     if (extra[0] <= 0 || extra[0] > (1 << 20) || extra[1] < rope_need || extra[1] > (1 << 20))
         return fail("gdx_import_packed: implausible table sizes");
@@ -767,7 +784,7 @@ static int forward_core(gdx_model* h, const float* x, const float* temb, int tst
 }
 
 // fp16 mode: one GEMM through gemmh.hip.  A [M][K16] halves with exactly M readable rows.
-static int gemm_f16(const _Float16* A, int lda, const Packed& P, const float* bias, const float* R, int ldr,
+static int gemm_f16(bool bf, const _Float16* A, int lda, const Packed& P, const float* bias, const float* R, int ldr,
                     const float* V, int ldv, float* C32, int ldc32, _Float16* C16, int ldc16, int M, int N, int T,
                     int rowmap, int gelu, hipStream_t s) {
     const size_t ab = (size_t)M * lda * 2, wb = (size_t)P.npad16 * P.kpad16 * 2;
@@ -775,7 +792,7 @@ static int gemm_f16(const _Float16* A, int lda, const Packed& P, const float* bi
     if (N > P.npad16) return fail("gemm_f16: N exceeds the packed weight");
     GemmHParams p{A, lda, P.w16, P.kpad16, (int)ab, (int)wb, bias, R, ldr, V, ldv, C32, ldc32, C16, ldc16,
                   M, N, P.kpad16, T, rowmap, gelu};
-    hipError_t e = launch_gemmh(p, s);
+    hipError_t e = HFN(bf, launch_gemmh, p, s);
     if (e != hipSuccess) return fail(std::string("launch_gemmh: ") + hipGetErrorString(e));
     return 0;
 }
@@ -792,26 +809,26 @@ static int forward_core_f16(gdx_model* h, const float* x, const float* temb, int
     const int N = Beff * S;
     const int Jp = h->in_x.kpad16;
     float* const tap32 = h->keep_taps ? h->xa : nullptr;              // fp32 copies only for the parity taps
-    HIPCHK(launch_transpose_in_f16(x, h->xt16, Beff, B, J, T, Jp, s));
+    HIPCHK(HFN(h->bf16, launch_transpose_in_f16, x, h->xt16, Beff, B, J, T, Jp, s));
     if (h->cfg.arch == GDX_ARCH_MDM_OLD) {
-        HIPCHK(launch_token0(temb, tstride, seed_emb, h->pe, h->xa, h->xa16, nullptr, nullptr, nullptr, state, Beff, B, S, d, s));
-        if (gemm_f16(h->xt16, Jp, h->in_x, nullptr, h->addend, d, nullptr, 0, tap32, d, h->xa16, d, Beff * T, d, T, 1, 0, s))
+        HIPCHK(HFN(h->bf16, launch_token0, temb, tstride, seed_emb, h->pe, h->xa, h->xa16, nullptr, nullptr, nullptr, state, Beff, B, S, d, s));
+        if (gemm_f16(h->bf16, h->xt16, Jp, h->in_x, nullptr, h->addend, d, nullptr, 0, tap32, d, h->xa16, d, Beff * T, d, T, 1, 0, s))
             return -1;
     } else {
         if (!c2t) return fail("forward_core: V2 needs the W_coa * temb rows");
         const float* c2s = mode == GDX_UNCOND ? h->c2_seed + (size_t)B * d : h->c2_seed;
-        HIPCHK(launch_token0(temb, tstride, seed_emb, nullptr, h->xa, h->xa16, c2t, c2s, h->c2, state, Beff, B, S, d, s));
-        if (gemm_f16(h->xt16, Jp, h->in_x, h->in_x.bias, nullptr, 0, nullptr, 0, nullptr, 0, h->emb16, d, Beff * T, d, T, 0, 0, s))
+        HIPCHK(HFN(h->bf16, launch_token0, temb, tstride, seed_emb, nullptr, h->xa, h->xa16, c2t, c2s, h->c2, state, Beff, B, S, d, s));
+        if (gemm_f16(h->bf16, h->xt16, Jp, h->in_x, h->in_x.bias, nullptr, 0, nullptr, 0, nullptr, 0, h->emb16, d, Beff * T, d, T, 0, 0, s))
             return -1;
-        if (local_attention_f16_supported(d, h->cfg.cl_head, h->cfg.window)) {
-            if (gemm_f16(h->emb16, d, h->proj_pose, nullptr, h->addend, d, h->c2, d, nullptr, 0, h->xseq16, d, Beff * T, d, T, 0, 0, s))
+        if (HFN(h->bf16, local_attention_f16_supported, d, h->cfg.cl_head, h->cfg.window)) {
+            if (gemm_f16(h->bf16, h->emb16, d, h->proj_pose, nullptr, h->addend, d, h->c2, d, nullptr, 0, h->xseq16, d, Beff * T, d, T, 0, 0, s))
                 return -1;
-            HIPCHK(launch_local_attention_f16(h->xseq16, h->rope_cos, h->rope_sin, h->xa16, tap32, Beff, T, d,
+            HIPCHK(HFN(h->bf16, launch_local_attention_f16, h->xseq16, h->rope_cos, h->rope_sin, h->xa16, tap32, Beff, T, d,
                                               h->cfg.cl_head, h->cfg.window, s));
         } else {
-            if (gemm_f16(h->emb16, d, h->proj_pose, nullptr, h->addend, d, h->c2, d, h->xseq, d, nullptr, 0, Beff * T, d, T, 0, 0, s))
+            if (gemm_f16(h->bf16, h->emb16, d, h->proj_pose, nullptr, h->addend, d, h->c2, d, h->xseq, d, nullptr, 0, Beff * T, d, T, 0, 0, s))
                 return -1;
-            HIPCHK(launch_local_attention(h->xseq, h->rope_cos, h->rope_sin, h->xa, h->xa16, Beff, T, d, h->cfg.cl_head,
+            HIPCHK(HFN(h->bf16, launch_local_attention, h->xseq, h->rope_cos, h->rope_sin, h->xa, h->xa16, Beff, T, d, h->cfg.cl_head,
                                           h->cfg.window, s));
         }
     }
@@ -819,28 +836,28 @@ static int forward_core_f16(gdx_model* h, const float* x, const float* temb, int
         HIPCHK(hipMemcpyAsync(h->taps[0], h->xa, sizeof(float) * (size_t)N * d, hipMemcpyDeviceToDevice, s));
     for (int l = 0; l < h->L; ++l) {
         const Layer& ly = h->layers[l];
-        if (gemm_f16(h->xa16, d, ly.qkv, ly.qkv.bias, nullptr, 0, nullptr, 0, nullptr, 0, h->qkv16, 3 * d, N, 3 * d, T, 0, 0, s))
+        if (gemm_f16(h->bf16, h->xa16, d, ly.qkv, ly.qkv.bias, nullptr, 0, nullptr, 0, nullptr, 0, h->qkv16, 3 * d, N, 3 * d, T, 0, 0, s))
             return -1;
-        HIPCHK(launch_attentionh(h->qkv16, h->ctx16, Beff, S, h->H, d, h->rows_alloc, s));
-        if (gemm_f16(h->ctx16, d, ly.out, ly.out.bias, nullptr, 0, nullptr, 0, nullptr, 0, h->tmp16, d, N, d, T, 0, 0, s)) return -1;
-        HIPCHK(launch_layernorm_f16(h->tmp16, h->xa16, ly.g1, ly.b1, h->xb16, nullptr, N, d, 0, s));
+        HIPCHK(HFN(h->bf16, launch_attentionh, h->qkv16, h->ctx16, Beff, S, h->H, d, h->rows_alloc, s));
+        if (gemm_f16(h->bf16, h->ctx16, d, ly.out, ly.out.bias, nullptr, 0, nullptr, 0, nullptr, 0, h->tmp16, d, N, d, T, 0, 0, s)) return -1;
+        HIPCHK(HFN(h->bf16, launch_layernorm_f16, h->tmp16, h->xa16, ly.g1, ly.b1, h->xb16, nullptr, N, d, 0, s));
         const bool stamp = h->prof && h->prof_used + 2 <= h->prof_ev.size();
         if (stamp) HIPCHK(hipEventRecord(h->prof_ev[h->prof_used], s));
-        if (gemm_f16(h->xb16, d, ly.ff1, ly.ff1.bias, nullptr, 0, nullptr, 0, nullptr, 0, h->ffb16, h->ff, N, h->ff, T, 0, 1, s))
+        if (gemm_f16(h->bf16, h->xb16, d, ly.ff1, ly.ff1.bias, nullptr, 0, nullptr, 0, nullptr, 0, h->ffb16, h->ff, N, h->ff, T, 0, 1, s))
             return -1;
         if (stamp) {
             HIPCHK(hipEventRecord(h->prof_ev[h->prof_used + 1], s));
             h->prof_used += 2;
         }
-        if (gemm_f16(h->ffb16, h->ff, ly.ff2, ly.ff2.bias, nullptr, 0, nullptr, 0, nullptr, 0, h->tmp16, d, N, d, T, 0, 0, s))
+        if (gemm_f16(h->bf16, h->ffb16, h->ff, ly.ff2, ly.ff2.bias, nullptr, 0, nullptr, 0, nullptr, 0, h->tmp16, d, N, d, T, 0, 0, s))
             return -1;
         const bool last = l + 1 == h->L;
-        if (!last || h->keep_taps) HIPCHK(launch_layernorm_f16(h->tmp16, h->xb16, ly.g2, ly.b2, h->xa16, tap32, N, d, 0, s));
-        if (last) HIPCHK(launch_layernorm_f16(h->tmp16, h->xb16, ly.g2, ly.b2, h->xc16, nullptr, N, d, S, s));
+        if (!last || h->keep_taps) HIPCHK(HFN(h->bf16, launch_layernorm_f16, h->tmp16, h->xb16, ly.g2, ly.b2, h->xa16, tap32, N, d, 0, s));
+        if (last) HIPCHK(HFN(h->bf16, launch_layernorm_f16, h->tmp16, h->xb16, ly.g2, ly.b2, h->xc16, nullptr, N, d, S, s));
         if (h->keep_taps)
             HIPCHK(hipMemcpyAsync(h->taps[l + 1], h->xa, sizeof(float) * (size_t)N * d, hipMemcpyDeviceToDevice, s));
     }
-    if (gemm_f16(h->xc16, d, h->outp, h->outp.bias, nullptr, 0, nullptr, 0, h->x0t, h->ldo, nullptr, 0, Beff * T, h->ldo, T, 0, 0, s))
+    if (gemm_f16(h->bf16, h->xc16, d, h->outp, h->outp.bias, nullptr, 0, nullptr, 0, h->x0t, h->ldo, nullptr, 0, Beff * T, h->ldo, T, 0, 0, s))
         return -1;
     HIPCHK(launch_transpose_out(h->x0t, x0_out, Beff, J, T, h->ldo, s));
     return 0;
@@ -1202,6 +1219,12 @@ extern "C" int gdx_bench_gemm(int32_t M, int32_t N, int32_t K, int32_t epi, int3
     return 0;
 }
 
+extern "C" int gdx_set_test_half_dtype(int32_t dtype) {
+    if (dtype != GDX_DTYPE_F16 && dtype != GDX_DTYPE_BF16) return fail("gdx_set_test_half_dtype: GDX_DTYPE_F16 or GDX_DTYPE_BF16");
+    g_test_bf16 = dtype == GDX_DTYPE_BF16;
+    return 0;
+}
+
 extern "C" int gdx_linear_f16(const float* A, const float* W, const float* bias, float* C32, float* C16, int32_t M,
                               int32_t N, int32_t K, int32_t gelu, void* stream) {
     if (!A || !W || (!C32 && !C16) || M <= 0 || N <= 0 || K <= 0 || K % 64 || N % 64)
@@ -1214,22 +1237,22 @@ extern "C" int gdx_linear_f16(const float* A, const float* W, const float* bias,
     if (dev_alloc(pool, (void**)&a16, 2 * (size_t)M * K) || dev_alloc(pool, (void**)&w16, 2 * (size_t)npad * K) ||
         dev_alloc(pool, (void**)&c16, 2 * (size_t)M * N))
         rc = -1;
-    if (!rc && launch_convert_f16(A, a16, (int64_t)M * K, s) != hipSuccess) rc = fail("gdx_linear_f16: convert failed");
-    if (!rc) rc = pack_f16_into(w16, W, N, K, 0, K, npad, K, s);
+    if (!rc && HFN(g_test_bf16, launch_convert_f16, A, a16, (int64_t)M * K, s) != hipSuccess) rc = fail("gdx_linear_f16: convert failed");
+    if (!rc) rc = pack_f16_into(w16, W, N, K, 0, K, npad, K, s, g_test_bf16);
     if (!rc) {
         GemmHParams p{a16, K, w16, K, (int)((size_t)M * K * 2), (int)((size_t)npad * K * 2), bias, nullptr, 0, nullptr, 0,
                       C32, N, C16 ? c16 : nullptr, N, M, N, K, 1, 0, gelu};
-        hipError_t e = launch_gemmh(p, s);
+        hipError_t e = HFN(g_test_bf16, launch_gemmh, p, s);
         if (e != hipSuccess) rc = fail(std::string("launch_gemmh: ") + hipGetErrorString(e));
     }
-    if (!rc && C16 && launch_convert_f32(c16, C16, (int64_t)M * N, s) != hipSuccess) rc = fail("gdx_linear_f16: convert failed");
+    if (!rc && C16 && HFN(g_test_bf16, launch_convert_f32, c16, C16, (int64_t)M * N, s) != hipSuccess) rc = fail("gdx_linear_f16: convert failed");
     (void)hipStreamSynchronize(s);
     free_pool(pool);
     return rc;
 }
 
 extern "C" int gdx_attention_f16(const float* qkv, float* ctx, int32_t B, int32_t S, int32_t H, int32_t d, void* stream) {
-    if (!qkv || !ctx || B <= 0 || S <= 0 || H <= 0 || d <= 0 || d % H || !attentionh_supported(S, H, d))
+    if (!qkv || !ctx || B <= 0 || S <= 0 || H <= 0 || d <= 0 || d % H || !HFN(g_test_bf16, attentionh_supported, S, H, d))
         return fail("gdx_attention_f16: bad argument / unsupported shape");
     hipStream_t s = (hipStream_t)stream;
     const size_t rows = (size_t)B * S;
@@ -1237,12 +1260,12 @@ extern "C" int gdx_attention_f16(const float* qkv, float* ctx, int32_t B, int32_
     std::vector<void*> pool;
     int rc = 0;
     if (dev_alloc(pool, (void**)&q16, 2 * rows * 3 * d) || dev_alloc(pool, (void**)&c16, 2 * rows * d)) rc = -1;
-    if (!rc && launch_convert_f16(qkv, q16, (int64_t)rows * 3 * d, s) != hipSuccess) rc = fail("gdx_attention_f16: convert failed");
+    if (!rc && HFN(g_test_bf16, launch_convert_f16, qkv, q16, (int64_t)rows * 3 * d, s) != hipSuccess) rc = fail("gdx_attention_f16: convert failed");
     if (!rc) {
-        hipError_t e = launch_attentionh(q16, c16, B, S, H, d, (long)rows, s);
+        hipError_t e = HFN(g_test_bf16, launch_attentionh, q16, c16, B, S, H, d, (long)rows, s);
         if (e != hipSuccess) rc = fail(std::string("launch_attentionh: ") + hipGetErrorString(e));
     }
-    if (!rc && launch_convert_f32(c16, ctx, (int64_t)rows * d, s) != hipSuccess) rc = fail("gdx_attention_f16: convert failed");
+    if (!rc && HFN(g_test_bf16, launch_convert_f32, c16, ctx, (int64_t)rows * d, s) != hipSuccess) rc = fail("gdx_attention_f16: convert failed");
     (void)hipStreamSynchronize(s);
     free_pool(pool);
     return rc;
@@ -1296,8 +1319,8 @@ extern "C" int gdx_bench_gemm_f16(int32_t M, int32_t N, int32_t K, int32_t gelu,
     }
     int rc = 0;
     // non-trivial operand values (zero operands raise the clock: cdna_hip_programming.md rule 25)
-    if (gdx_randn(Af, 1, (int64_t)M * K, 1, 0, 0, stream) || launch_convert_f16(Af, a16, (int64_t)M * K, s) != hipSuccess ||
-        gdx_randn(Af, 1, (int64_t)npad * K, 2, 0, 0, stream) || launch_convert_f16(Af, w16, (int64_t)npad * K, s) != hipSuccess ||
+    if (gdx_randn(Af, 1, (int64_t)M * K, 1, 0, 0, stream) || HFN(g_test_bf16, launch_convert_f16, Af, a16, (int64_t)M * K, s) != hipSuccess ||
+        gdx_randn(Af, 1, (int64_t)npad * K, 2, 0, 0, stream) || HFN(g_test_bf16, launch_convert_f16, Af, w16, (int64_t)npad * K, s) != hipSuccess ||
         gdx_randn(bias, 1, npad, 4, 0, 0, stream))
         rc = fail("gdx_bench_gemm_f16: operand fill failed");
     GemmHParams p{a16, K, w16, K, (int)((size_t)M * K * 2), (int)((size_t)npad * K * 2), bias, nullptr, 0, nullptr, 0,
@@ -1305,10 +1328,10 @@ extern "C" int gdx_bench_gemm_f16(int32_t M, int32_t N, int32_t K, int32_t gelu,
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (!rc && (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess)) rc = fail("hipEventCreate failed");
     for (int i = 0; !rc && i < 3; ++i)
-        if (launch_gemmh(p, s) != hipSuccess) rc = fail("launch_gemmh failed");
+        if (HFN(g_test_bf16, launch_gemmh, p, s) != hipSuccess) rc = fail("launch_gemmh failed");
     if (!rc) (void)hipEventRecord(e0, s);
     for (int i = 0; !rc && i < iters; ++i)
-        if (launch_gemmh(p, s) != hipSuccess) rc = fail("launch_gemmh failed");
+        if (HFN(g_test_bf16, launch_gemmh, p, s) != hipSuccess) rc = fail("launch_gemmh failed");
     if (!rc) {
         (void)hipEventRecord(e1, s);
         (void)hipEventSynchronize(e1);
@@ -1323,7 +1346,7 @@ extern "C" int gdx_bench_gemm_f16(int32_t M, int32_t N, int32_t K, int32_t gelu,
         if (!dev_alloc(pool, (void**)&dd, 512)) {
             (void)hipMemsetAsync(dd, 0, 512, s);
             g2_dbg_buf = dd;
-            (void)launch_gemmh(p, s);
+            (void)HFN(g_test_bf16, launch_gemmh, p, s);
             g2_dbg_buf = nullptr;
             unsigned long long hh[48] = {0};
             (void)hipMemcpyAsync(hh, dd, 384, hipMemcpyDeviceToHost, s);
@@ -1359,15 +1382,15 @@ extern "C" int gdx_bench_attention(int32_t B, int32_t S, int32_t H, int32_t d, i
     HIPCHK(gdx_randn(qkv, 1, (int64_t)rows * 3 * d, 5, 0, 0, stream) ? hipErrorUnknown : hipSuccess);
     _Float16 *qkv16 = nullptr, *ctx16 = nullptr;
     if (version == 3) {
-        if (!attentionh_supported(S, H, d)) { free_pool(pool); return fail("gdx_bench_attention: shape not supported by the fp16 kernel"); }
+        if (!HFN(g_test_bf16, attentionh_supported, S, H, d)) { free_pool(pool); return fail("gdx_bench_attention: shape not supported by the fp16 kernel"); }
         if (dev_alloc(pool, (void**)&qkv16, 2 * rows * 3 * d) || dev_alloc(pool, (void**)&ctx16, 2 * rows * d)) {
             free_pool(pool);
             return -1;
         }
-        HIPCHK(launch_convert_f16(qkv, qkv16, (int64_t)rows * 3 * d, s));
+        HIPCHK(HFN(g_test_bf16, launch_convert_f16, qkv, qkv16, (int64_t)rows * 3 * d, s));
     }
     auto run = [&]() -> hipError_t {
-        if (version == 3) return launch_attentionh(qkv16, ctx16, B, S, H, d, (long)rows, s);
+        if (version == 3) return HFN(g_test_bf16, launch_attentionh, qkv16, ctx16, B, S, H, d, (long)rows, s);
         if (version == 4 && attention3_supported(S, H, d)) return launch_attention3(qkv, ctx, B, S, H, d, s);
         if (version == 2 && attention2_supported(S, H, d)) return launch_attention2(qkv, ctx, B, S, H, d, s);
         return launch_attention(qkv, ctx, B, S, H, d, s);

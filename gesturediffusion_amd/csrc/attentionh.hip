@@ -25,10 +25,17 @@
 #include <cstdlib>
 #include <type_traits>
 
-namespace gdx {
+#ifdef GDX_BF16
+#define GDX_MFMA16 __builtin_amdgcn_mfma_f32_16x16x32_bf16
+#else
+#define GDX_MFMA16 __builtin_amdgcn_mfma_f32_16x16x32_f16
+#endif
 
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+namespace gdx {
+GDX_HNS_BEGIN
+
+typedef half_t f16x8 __attribute__((ext_vector_type(8)));
+typedef half_t f16x4 __attribute__((ext_vector_type(4)));
 typedef __fp16 fp16x4_t __attribute__((__vector_size__(4 * sizeof(__fp16))));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
@@ -177,7 +184,7 @@ __global__ __launch_bounds__(512, 1) void attentionh_kernel(const _Float16* __re
                     if (r + PD < NR) kring[(r + PD) % (PD + 1)] = kread(r + PD);
 #pragma unroll
                     for (int qi = 0; qi < NQ; ++qi)
-                        s[qi][r / NKS] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kring[r % (PD + 1)], qf[qi][r % NKS], s[qi][r / NKS], 0, 0, 0);
+                        s[qi][r / NKS] = GDX_MFMA16(kring[r % (PD + 1)], qf[qi][r % NKS], s[qi][r / NKS], 0, 0, 0);
                 }
                 // the first V^T fragments are requested before the softmax so that their latency hides behind it
                 constexpr int VD = NNB < 4 ? NNB - 1 : 3;
@@ -221,8 +228,8 @@ __global__ __launch_bounds__(512, 1) void attentionh_kernel(const _Float16* __re
                         psum += v[j];
                     }
                     l_run[qi] += psum;
-                    pf[qi] = f16x8{(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3],
-                                   (_Float16)v[4], (_Float16)v[5], (_Float16)v[6], (_Float16)v[7]};
+                    pf[qi] = f16x8{(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3],
+                                   (half_t)v[4], (half_t)v[5], (half_t)v[6], (half_t)v[7]};
                 }
                 // ---- O^T += V^T P^T: transposed reads of V (keys 4lq.. of block 0, then of block 1) feed all query blocks
 #pragma unroll
@@ -235,7 +242,7 @@ __global__ __launch_bounds__(512, 1) void attentionh_kernel(const _Float16* __re
                     const f16x8 vf = f16x8{v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
 #pragma unroll
                     for (int qi = 0; qi < NQ; ++qi)
-                        o[qi][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pf[qi], o[qi][nb], 0, 0, 0);
+                        o[qi][nb] = GDX_MFMA16(vf, pf[qi], o[qi][nb], 0, 0, 0);
                 }
             }
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // tile consumed; the loaders waited for the next one
@@ -260,7 +267,7 @@ __global__ __launch_bounds__(512, 1) void attentionh_kernel(const _Float16* __re
 #pragma unroll
             for (int nb = 0; nb < NNB; ++nb) {
                 const f32x4 r = o[qi][nb] * inv;
-                *reinterpret_cast<f16x4*>(op + 16 * nb) = f16x4{(_Float16)r[0], (_Float16)r[1], (_Float16)r[2], (_Float16)r[3]};
+                *reinterpret_cast<f16x4*>(op + 16 * nb) = f16x4{(half_t)r[0], (half_t)r[1], (half_t)r[2], (half_t)r[3]};
             }
         }
     }
@@ -369,8 +376,8 @@ __global__ __launch_bounds__(512, 1) void attentionh8_kernel(const _Float16* __r
 #pragma unroll
             for (int r = 0; r < NR; ++r) {
                 if (r + PD < NR) kring[(r + PD) % (PD + 1)] = kread(r + PD);
-                if (r < NKS) s0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(kring[r % (PD + 1)], qf[r % NKS], s0, 0, 0, 0);
-                else s1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(kring[r % (PD + 1)], qf[r % NKS], s1, 0, 0, 0);
+                if (r < NKS) s0 = GDX_MFMA16(kring[r % (PD + 1)], qf[r % NKS], s0, 0, 0, 0);
+                else s1 = GDX_MFMA16(kring[r % (PD + 1)], qf[r % NKS], s1, 0, 0, 0);
             }
             constexpr int VD = NNB < 4 ? NNB - 1 : 3;
             auto vread = [&](int nb, int half) { return lds_read_tr(St + ((vbase + half * 16 * ROWB) ^ (nb << 5))); };
@@ -410,8 +417,8 @@ __global__ __launch_bounds__(512, 1) void attentionh8_kernel(const _Float16* __r
                 psum += v[j];
             }
             l_run += psum;
-            const f16x8 pf = f16x8{(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3],
-                                   (_Float16)v[4], (_Float16)v[5], (_Float16)v[6], (_Float16)v[7]};
+            const f16x8 pf = f16x8{(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3],
+                                   (half_t)v[4], (half_t)v[5], (half_t)v[6], (half_t)v[7]};
 #pragma unroll
             for (int nb = 0; nb < NNB; ++nb) {
                 if (nb + VD < NNB) {
@@ -420,7 +427,7 @@ __global__ __launch_bounds__(512, 1) void attentionh8_kernel(const _Float16* __r
                 }
                 const f16x4 v0 = vring[nb % (VD + 1)][0], v1 = vring[nb % (VD + 1)][1];
                 const f16x8 vf = f16x8{v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-                o[nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pf, o[nb], 0, 0, 0);
+                o[nb] = GDX_MFMA16(vf, pf, o[nb], 0, 0, 0);
             }
         }
         ah_wait_vm<(NST - 2) * PW>();                                 // this wave's pieces of tile kt+1
@@ -441,7 +448,7 @@ __global__ __launch_bounds__(512, 1) void attentionh8_kernel(const _Float16* __r
 #pragma unroll
             for (int nb = 0; nb < NNB; ++nb) {
                 const f32x4 r = o[nb] * inv;
-                *reinterpret_cast<f16x4*>(op + 16 * nb) = f16x4{(_Float16)r[0], (_Float16)r[1], (_Float16)r[2], (_Float16)r[3]};
+                *reinterpret_cast<f16x4*>(op + 16 * nb) = f16x4{(half_t)r[0], (half_t)r[1], (half_t)r[2], (half_t)r[3]};
             }
         }
     }
@@ -560,7 +567,7 @@ __global__ __launch_bounds__(512, 1) void attentionh8q_kernel(const _Float16* __
                     if (r + PD < NR) kring[(r + PD) % (PD + 1)] = kread(r + PD);
 #pragma unroll
                     for (int qi = 0; qi < NQ; ++qi)
-                        s[qi][r / NKS] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kring[r % (PD + 1)], qf[qi][r % NKS], s[qi][r / NKS], 0, 0, 0);
+                        s[qi][r / NKS] = GDX_MFMA16(kring[r % (PD + 1)], qf[qi][r % NKS], s[qi][r / NKS], 0, 0, 0);
                 }
                 constexpr int VD = NNB < 4 ? NNB - 1 : 3;
                 auto vread = [&](int nb, int half) { return lds_read_tr(St + ((vbase + half * 16 * ROWB) ^ (nb << 5))); };
@@ -602,8 +609,8 @@ __global__ __launch_bounds__(512, 1) void attentionh8q_kernel(const _Float16* __
                         psum += v[j];
                     }
                     l_run[qi] += psum;
-                    pf[qi] = f16x8{(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3],
-                                   (_Float16)v[4], (_Float16)v[5], (_Float16)v[6], (_Float16)v[7]};
+                    pf[qi] = f16x8{(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3],
+                                   (half_t)v[4], (half_t)v[5], (half_t)v[6], (half_t)v[7]};
                 }
 #pragma unroll
                 for (int nb = 0; nb < NNB; ++nb) {
@@ -615,7 +622,7 @@ __global__ __launch_bounds__(512, 1) void attentionh8q_kernel(const _Float16* __
                     const f16x8 vf = f16x8{v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
 #pragma unroll
                     for (int qi = 0; qi < NQ; ++qi)
-                        o[qi][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pf[qi], o[qi][nb], 0, 0, 0);
+                        o[qi][nb] = GDX_MFMA16(vf, pf[qi], o[qi][nb], 0, 0, 0);
                 }
             }
             ah_wait_vm<(NST - 2) * PW>();
@@ -642,7 +649,7 @@ __global__ __launch_bounds__(512, 1) void attentionh8q_kernel(const _Float16* __
 #pragma unroll
             for (int nb = 0; nb < NNB; ++nb) {
                 const f32x4 r = o[qi][nb] * inv;
-                *reinterpret_cast<f16x4*>(op + 16 * nb) = f16x4{(_Float16)r[0], (_Float16)r[1], (_Float16)r[2], (_Float16)r[3]};
+                *reinterpret_cast<f16x4*>(op + 16 * nb) = f16x4{(half_t)r[0], (half_t)r[1], (half_t)r[2], (half_t)r[3]};
             }
         }
     }
@@ -737,4 +744,5 @@ hipError_t launch_attentionh(const _Float16* qkv, _Float16* ctx, int B, int S, i
     return hipErrorInvalidValue;
 }
 
+GDX_HNS_END
 }  // namespace gdx

@@ -28,12 +28,21 @@
 #include <cstdlib>
 #include <type_traits>
 
+#ifdef GDX_BF16
+#define GDX_MFMA16 __builtin_amdgcn_mfma_f32_16x16x32_bf16
+#else
+#define GDX_MFMA16 __builtin_amdgcn_mfma_f32_16x16x32_f16
+#endif
+
 namespace gdx {
 
 extern unsigned long long* g2_dbg_buf;   // gemm2.hip: set by the bench helpers when GDX_GEMM_DEBUG is set
+int gemm2_num_cus();
 
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+GDX_HNS_BEGIN
+
+typedef half_t f16x8 __attribute__((ext_vector_type(8)));
+typedef half_t f16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
@@ -129,13 +138,13 @@ __device__ __forceinline__ void wave_epilogue_impl(const GemmHParams& p, f32x4 (
                 _Float16* cp = pC16 + ro * p.ldc16 + nb;
                 if constexpr (NBW == 1) {
                     *reinterpret_cast<f16x4*>(cp) =
-                        f16x4{(_Float16)v[0][0], (_Float16)v[0][1], (_Float16)v[0][2], (_Float16)v[0][3]};
+                        f16x4{(half_t)v[0][0], (half_t)v[0][1], (half_t)v[0][2], (half_t)v[0][3]};
                 } else {
 #pragma unroll
                     for (int j = 0; j < NBW; j += 2)
                         *reinterpret_cast<f16x8*>(cp + CM::blk(j)) =
-                            f16x8{(_Float16)v[j][0],     (_Float16)v[j][1],     (_Float16)v[j][2],     (_Float16)v[j][3],
-                                  (_Float16)v[j + 1][0], (_Float16)v[j + 1][1], (_Float16)v[j + 1][2], (_Float16)v[j + 1][3]};
+                            f16x8{(half_t)v[j][0],     (half_t)v[j][1],     (half_t)v[j][2],     (half_t)v[j][3],
+                                  (half_t)v[j + 1][0], (half_t)v[j + 1][1], (half_t)v[j + 1][2], (half_t)v[j + 1][3]};
                 }
             }
         }
@@ -295,7 +304,7 @@ __global__ __launch_bounds__(512, 1) void gemmh_kernel(const GemmHParams p, cons
         for (int i = 0; i < MB; ++i)
 #pragma unroll
             for (int j = 0; j < NBW; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fw[j], fa[i], acc[i][j], 0, 0, 0);
+                acc[i][j] = GDX_MFMA16(fw[j], fa[i], acc[i][j], 0, 0, 0);
     };
     int ks = 0, stage = 0, tile_i = 0;
     auto epilogue = [&]() {
@@ -448,7 +457,7 @@ __global__ __launch_bounds__(512, 1) void gemmh8_kernel(const GemmHParams p, con
         for (int i = 0; i < MB; ++i)
 #pragma unroll
             for (int j = 0; j < NBW; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fw[j], fa[i], acc[i][j], 0, 0, 0);
+                acc[i][j] = GDX_MFMA16(fw[j], fa[i], acc[i][j], 0, 0, 0);
     };
     auto step_sync = [&]() {
         __builtin_amdgcn_sched_barrier(0);
@@ -718,7 +727,7 @@ __global__ __launch_bounds__(512, 1) void gemmh8b_kernel(const GemmHParams p, co
         for (int i = 0; i < MB; ++i)
 #pragma unroll
             for (int j = 0; j < NBW; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fw[j], fa[i], acc[i][j], 0, 0, 0);
+                acc[i][j] = GDX_MFMA16(fw[j], fa[i], acc[i][j], 0, 0, 0);
     };
     auto sync_wait = [&]() {                                      // end of step (j, 0): slab j+1 has landed
         __builtin_amdgcn_sched_barrier(0);
@@ -907,8 +916,6 @@ static double gh_cost(int mb, int nbw, int M, int N, int K, int num_cus, bool ge
     return rounds * ((K / 32) * gh_step_us(mb, nbw) + blocks * (gelu ? 0.1 : 0.03) + 0.5);
 }
 
-int gemm2_num_cus();
-
 bool gemmh_supported(const GemmHParams& p) {
     return p.A && p.W && p.K > 0 && p.K % 64 == 0 && p.N > 0 && p.N % 64 == 0 && p.N <= 8192 && p.lda % 8 == 0 &&
            p.ldw % 8 == 0 && p.a_bytes > 0 && p.w_bytes > 0 && (!p.C16 || p.ldc16 % 8 == 0) && (!p.C32 || p.ldc32 % 4 == 0) &&
@@ -949,7 +956,7 @@ static hipError_t launch_gh_choice(const GemmHParams& p, const GhChoice& c, int 
 }
 
 hipError_t launch_gemmh(const GemmHParams& p, hipStream_t s) {
-    if (!gemmh_supported(p)) return hipErrorInvalidValue;
+    if (!GDX_HNS_NAME::gemmh_supported(p)) return hipErrorInvalidValue;
     const int num_cus = gemm2_num_cus();
     static int force_mb = -1, force_nbw = -1;
     if (force_mb < 0) {
@@ -1001,4 +1008,5 @@ hipError_t launch_gemmh(const GemmHParams& p, hipStream_t s) {
     return launch_gh_choice(p, whole, num_cus, s);
 }
 
+GDX_HNS_END
 }  // namespace gdx

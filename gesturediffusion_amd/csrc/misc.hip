@@ -3,10 +3,17 @@
 // token, the fused V2 front end (RoPE -> causal local attention -> RoPE) and the CFG blend.
 #include "gdx_internal.h"
 
+#ifdef GDX_BF16
+#define GDX_MFMA16 __builtin_amdgcn_mfma_f32_16x16x32_bf16
+#else
+#define GDX_MFMA16 __builtin_amdgcn_mfma_f32_16x16x32_f16
+#endif
+
 namespace gdx {
+GDX_HNS_BEGIN
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef half_t f16x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
@@ -23,7 +30,7 @@ template <int VPL>   // float4 per lane: d = 256 * VPL
 __global__ __launch_bounds__(256) void layernorm_vec_kernel(const float* __restrict__ x, const float* __restrict__ res,
                                                              const float* __restrict__ g,
                                                              const float* __restrict__ bta, float* __restrict__ out,
-                                                             _Float16* __restrict__ out16, int rows, int d,
+                                                             half_t* __restrict__ out16, int rows, int d,
                                                              int compact_S) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
@@ -65,7 +72,7 @@ __global__ __launch_bounds__(256) void layernorm_vec_kernel(const float* __restr
 #pragma unroll
         for (int e = 0; e < 4; ++e) r[e] = (v[i][e] - mean) * rstd * gg[e] + bb[e];
         if (out) op[lane + 64 * i] = r;
-        if (out16) hp[lane + 64 * i] = f16x4{(_Float16)r[0], (_Float16)r[1], (_Float16)r[2], (_Float16)r[3]};
+        if (out16) hp[lane + 64 * i] = f16x4{(half_t)r[0], (half_t)r[1], (half_t)r[2], (half_t)r[3]};
     }
 }
 
@@ -73,7 +80,7 @@ __global__ __launch_bounds__(256) void layernorm_vec_kernel(const float* __restr
 __global__ __launch_bounds__(256) void layernorm_gen_kernel(const float* __restrict__ x, const float* __restrict__ res,
                                                              const float* __restrict__ g,
                                                              const float* __restrict__ bta, float* __restrict__ out,
-                                                             _Float16* __restrict__ out16, int rows, int d,
+                                                             half_t* __restrict__ out16, int rows, int d,
                                                              int compact_S) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
@@ -98,12 +105,13 @@ __global__ __launch_bounds__(256) void layernorm_gen_kernel(const float* __restr
     for (int e = lane; e < d; e += 64) {
         const float r = ((res ? xp[e] + rp[e] : xp[e]) - mean) * rstd * g[e] + bta[e];
         if (out) out[orow * d + e] = r;
-        if (out16) out16[orow * d + e] = (_Float16)r;
+        if (out16) out16[orow * d + e] = (half_t)r;
     }
 }
 
 hipError_t launch_layernorm(const float* x, const float* res, const float* gamma, const float* beta, float* out,
-                            _Float16* out16, int rows, int d, int compact_S, hipStream_t s) {
+                            _Float16* out16_, int rows, int d, int compact_S, hipStream_t s) {
+    half_t* out16 = reinterpret_cast<half_t*>(out16_);
     const dim3 grid((rows + 3) / 4), block(256);
     if (d == 512)
         hipLaunchKernelGGL(layernorm_vec_kernel<2>, grid, block, 0, s, x, res, gamma, beta, out, out16, rows, d, compact_S);
@@ -119,12 +127,12 @@ hipError_t launch_layernorm(const float* x, const float* res, const float* gamma
 // fp16-mode LayerNorm: x and the residual are fp16 (the whole activation stream of the fp16 mode is fp16), statistics
 // and the affine transform are fp32, output fp16 (+ optional fp32 copy for the parity taps).  One wave per row,
 // 8 halves (16 B) per lane per load.  HBM-bound: 3 * rows * d * 2 bytes.
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef half_t f16x8 __attribute__((ext_vector_type(8)));
 
 template <int NV>   // 16-byte loads per lane: d = 512 * NV
-__global__ __launch_bounds__(256) void layernorm_h_vec_kernel(const _Float16* __restrict__ x, const _Float16* __restrict__ res,
+__global__ __launch_bounds__(256) void layernorm_h_vec_kernel(const half_t* __restrict__ x, const half_t* __restrict__ res,
                                                                const float* __restrict__ g, const float* __restrict__ bta,
-                                                               _Float16* __restrict__ out16, float* __restrict__ out32,
+                                                               half_t* __restrict__ out16, float* __restrict__ out32,
                                                                int rows, int d, int compact_S) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
@@ -173,7 +181,7 @@ __global__ __launch_bounds__(256) void layernorm_h_vec_kernel(const _Float16* __
             r[4 + e] = (v[i][4 + e] - mean) * rstd * g1[e] + b1[e];
         }
         reinterpret_cast<f16x8*>(out16 + orow * d)[lane + 64 * i] =
-            f16x8{(_Float16)r[0], (_Float16)r[1], (_Float16)r[2], (_Float16)r[3], (_Float16)r[4], (_Float16)r[5], (_Float16)r[6], (_Float16)r[7]};
+            f16x8{(half_t)r[0], (half_t)r[1], (half_t)r[2], (half_t)r[3], (half_t)r[4], (half_t)r[5], (half_t)r[6], (half_t)r[7]};
         if (out32) {
             f32x4* op = reinterpret_cast<f32x4*>(out32 + orow * d);
             op[c4] = f32x4{r[0], r[1], r[2], r[3]};
@@ -182,9 +190,9 @@ __global__ __launch_bounds__(256) void layernorm_h_vec_kernel(const _Float16* __
     }
 }
 
-__global__ __launch_bounds__(256) void layernorm_h_gen_kernel(const _Float16* __restrict__ x, const _Float16* __restrict__ res,
+__global__ __launch_bounds__(256) void layernorm_h_gen_kernel(const half_t* __restrict__ x, const half_t* __restrict__ res,
                                                                const float* __restrict__ g, const float* __restrict__ bta,
-                                                               _Float16* __restrict__ out16, float* __restrict__ out32,
+                                                               half_t* __restrict__ out16, float* __restrict__ out32,
                                                                int rows, int d, int compact_S) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
@@ -195,8 +203,8 @@ __global__ __launch_bounds__(256) void layernorm_h_gen_kernel(const _Float16* __
         if (row - b * compact_S == 0) return;
         orow = row - b - 1;
     }
-    const _Float16* xp = x + (long)row * d;
-    const _Float16* rp = res + (long)row * d;
+    const half_t* xp = x + (long)row * d;
+    const half_t* rp = res + (long)row * d;
     auto at = [&](int e) { return res ? (float)xp[e] + (float)rp[e] : (float)xp[e]; };
     float s = 0.0f;
     for (int e = lane; e < d; e += 64) s += at(e);
@@ -209,13 +217,16 @@ __global__ __launch_bounds__(256) void layernorm_h_gen_kernel(const _Float16* __
     const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)d + 1e-5f);
     for (int e = lane; e < d; e += 64) {
         const float r = (at(e) - mean) * rstd * g[e] + bta[e];
-        out16[orow * d + e] = (_Float16)r;
+        out16[orow * d + e] = (half_t)r;
         if (out32) out32[orow * d + e] = r;
     }
 }
 
-hipError_t launch_layernorm_f16(const _Float16* x, const _Float16* res, const float* gamma, const float* beta,
-                                _Float16* out16, float* out32, int rows, int d, int compact_S, hipStream_t s) {
+hipError_t launch_layernorm_f16(const _Float16* x_, const _Float16* res_, const float* gamma, const float* beta,
+                                _Float16* out16_, float* out32, int rows, int d, int compact_S, hipStream_t s) {
+    const half_t* x = reinterpret_cast<const half_t*>(x_);
+    const half_t* res = reinterpret_cast<const half_t*>(res_);
+    half_t* out16 = reinterpret_cast<half_t*>(out16_);
     const dim3 grid((rows + 3) / 4), block(256);
     if (d == 512)
         hipLaunchKernelGGL(layernorm_h_vec_kernel<1>, grid, block, 0, s, x, res, gamma, beta, out16, out32, rows, d, compact_S);
@@ -276,9 +287,10 @@ hipError_t launch_transpose_in(const float* x, float* xt, int B, int Bsrc, int J
     return hipGetLastError();
 }
 
-hipError_t launch_transpose_in_f16(const float* x, _Float16* xt, int B, int Bsrc, int J, int T, int ldx, hipStream_t s) {
+hipError_t launch_transpose_in_f16(const float* x, _Float16* xt_, int B, int Bsrc, int J, int T, int ldx, hipStream_t s) {
+    half_t* xt = reinterpret_cast<half_t*>(xt_);
     const dim3 grid((T + 31) / 32, (ldx + 31) / 32, B);
-    hipLaunchKernelGGL(transpose_in_kernel<_Float16>, grid, dim3(256), 0, s, x, xt, Bsrc, J, T, ldx);
+    hipLaunchKernelGGL(transpose_in_kernel<half_t>, grid, dim3(256), 0, s, x, xt, Bsrc, J, T, ldx);
     return hipGetLastError();
 }
 
@@ -365,7 +377,7 @@ hipError_t launch_mfcc_project(const float* mfcc, const float* W, int ldw, const
 
 // conditioning token (model/mdm_old.py:94-111: emb_t + emb_seed, then + pe[0]; model/mdm.py:154-160,197)
 __global__ void token0_kernel(const float* __restrict__ temb, int tstride, const float* __restrict__ seed_emb,
-                              const float* __restrict__ pe0, float* __restrict__ enc, _Float16* __restrict__ enc16,
+                              const float* __restrict__ pe0, float* __restrict__ enc, half_t* __restrict__ enc16,
                               const float* __restrict__ c2t, const float* __restrict__ c2_seed, float* __restrict__ c2,
                               const int* __restrict__ state, int B, int Bmod, int S, int d) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -380,12 +392,13 @@ __global__ void token0_kernel(const float* __restrict__ temb, int tstride, const
     if (c2) c2[i] = c2t[trow] + c2_seed[i];       // coarse slice of project_to_lat: W_coa temb + W_coa seed_emb
     if (pe0) v += pe0[n];
     enc[(long)b * S * d + n] = v;
-    if (enc16) enc16[(long)b * S * d + n] = (_Float16)v;
+    if (enc16) enc16[(long)b * S * d + n] = (half_t)v;
 }
 
 hipError_t launch_token0(const float* temb, int tstride, const float* seed_emb, const float* pe0, float* enc,
-                         _Float16* enc16, const float* c2t, const float* c2_seed, float* c2, const int* state, int B,
+                         _Float16* enc16_, const float* c2t, const float* c2_seed, float* c2, const int* state, int B,
                          int Bmod, int S, int d, hipStream_t s) {
+    half_t* enc16 = reinterpret_cast<half_t*>(enc16_);
     hipLaunchKernelGGL(token0_kernel, dim3((B * d + 255) / 256), dim3(256), 0, s, temb, tstride, seed_emb, pe0, enc,
                        enc16, c2t, c2_seed, c2, state, B, Bmod, S, d);
     return hipGetLastError();
@@ -402,7 +415,7 @@ hipError_t launch_token0(const float* temb, int tstride, const float* seed_emb, 
 __global__ __launch_bounds__(64) void local_attention_kernel(const float* __restrict__ xseq,
                                                              const float* __restrict__ cosT,
                                                              const float* __restrict__ sinT, float* __restrict__ enc,
-                                                             _Float16* __restrict__ enc16, int T, int d, int heads,
+                                                             half_t* __restrict__ enc16, int T, int d, int heads,
                                                              int window) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int e = d / heads, half = e >> 1;
@@ -472,12 +485,13 @@ __global__ __launch_bounds__(64) void local_attention_kernel(const float* __rest
         const int f = c < half ? c : c - half;
         const float v = x * cosT[pos * half + f] + rot * sinT[pos * half + f];
         eb[(long)pos * d + c] = v;
-        if (enc16) enc16[((long)b * (T + 1) + pos) * d + head * e + c] = (_Float16)v;
+        if (enc16) enc16[((long)b * (T + 1) + pos) * d + head * e + c] = (half_t)v;
     }
 }
 
 hipError_t launch_local_attention(const float* xseq, const float* cosT, const float* sinT, float* enc,
-                                  _Float16* enc16, int B, int T, int d, int heads, int window, hipStream_t s) {
+                                  _Float16* enc16_, int B, int T, int d, int heads, int window, hipStream_t s) {
+    half_t* enc16 = reinterpret_cast<half_t*>(enc16_);
     const int e = d / heads;
     const size_t lds = (size_t)(2 * window * (e + 1) + window * 2 * window + window * (e + 1)) * sizeof(float);
     const dim3 grid(B * heads * (T / window)), block(64);
@@ -496,14 +510,14 @@ hipError_t launch_local_attention(const float* xseq, const float* cosT, const fl
 //   * V^T fragments: the rotated key rows are parked in LDS (8 KiB per wave, chunk-swizzled like attentionh.hip)
 //     and read back with ds_read_b64_tr_b16;
 //   * second RoPE (position t+1) on the O^T accumulators, again in-lane; fp16 store into the encoder input.
-typedef _Float16 la_f16x8 __attribute__((ext_vector_type(8)));
+typedef half_t la_f16x8 __attribute__((ext_vector_type(8)));
 typedef __fp16 la_fp16x4_t __attribute__((__vector_size__(4 * sizeof(__fp16))));
 
 template <int E>
-__global__ __launch_bounds__(256) void local_attention_h_kernel(const _Float16* __restrict__ xseq,
+__global__ __launch_bounds__(256) void local_attention_h_kernel(const half_t* __restrict__ xseq,
                                                                 const float* __restrict__ cosT,
                                                                 const float* __restrict__ sinT,
-                                                                _Float16* __restrict__ enc16, float* __restrict__ enc32,
+                                                                half_t* __restrict__ enc16, float* __restrict__ enc32,
                                                                 int nwork, int T, int d, int heads, int window) {
     constexpr int HALF = E / 2, NKS = E / 32, NNB = E / 16, ROWB = E * 2;
     __shared__ __attribute__((aligned(16))) char sm_all[4 * 32 * ROWB];
@@ -518,13 +532,13 @@ __global__ __launch_bounds__(256) void local_attention_h_kernel(const _Float16* 
     const int k0 = w == 0 ? 0 : (w - 1) * window;
     const int q0 = w * window;
     const int nkeys = q0 + window - k0;               // window or 2*window (<= 32)
-    const _Float16* xb = xseq + ((long)b * T) * d + head * E;
+    const half_t* xb = xseq + ((long)b * T) * d + head * E;
     auto fswz = [](int row) { return E == 64 ? ((row >> 1) & 3) << 1 : (row & 7) << 1; };
 
     // rotated row -> NKS fragments (8 halves at head-dim 32*ks + 8*lq .. +7); rows past the sequence read row T-1
     auto load_rot = [&](int pos, la_f16x8 (&f)[NKS]) {
         const int pc = pos < T ? pos : T - 1;
-        const _Float16* row = xb + (long)pc * d + 8 * lq;
+        const half_t* row = xb + (long)pc * d + 8 * lq;
         float v[NKS][8];
 #pragma unroll
         for (int ks = 0; ks < NKS; ++ks) {
@@ -546,8 +560,8 @@ __global__ __launch_bounds__(256) void local_attention_h_kernel(const _Float16* 
         }
 #pragma unroll
         for (int ks = 0; ks < NKS; ++ks)
-            f[ks] = la_f16x8{(_Float16)v[ks][0], (_Float16)v[ks][1], (_Float16)v[ks][2], (_Float16)v[ks][3],
-                             (_Float16)v[ks][4], (_Float16)v[ks][5], (_Float16)v[ks][6], (_Float16)v[ks][7]};
+            f[ks] = la_f16x8{(half_t)v[ks][0], (half_t)v[ks][1], (half_t)v[ks][2], (half_t)v[ks][3],
+                             (half_t)v[ks][4], (half_t)v[ks][5], (half_t)v[ks][6], (half_t)v[ks][7]};
     };
     la_f16x8 kf[2][NKS], qf[NKS];
     load_rot(k0 + l15, kf[0]);
@@ -566,7 +580,7 @@ __global__ __launch_bounds__(256) void local_attention_h_kernel(const _Float16* 
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-        for (int ks = 0; ks < NKS; ++ks) s[kb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[kb][ks], qf[ks], s[kb], 0, 0, 0);
+        for (int ks = 0; ks < NKS; ++ks) s[kb] = GDX_MFMA16(kf[kb][ks], qf[ks], s[kb], 0, 0, 0);
     const float c_log2 = 1.4426950408889634f / sqrtf((float)E);
     float v[8];
     float mx = -INFINITY;
@@ -591,8 +605,8 @@ __global__ __launch_bounds__(256) void local_attention_h_kernel(const _Float16* 
     sum += __shfl_xor(sum, 16);
     sum += __shfl_xor(sum, 32);
     const float inv = 1.0f / sum;
-    const la_f16x8 pf = la_f16x8{(_Float16)(v[0] * inv), (_Float16)(v[1] * inv), (_Float16)(v[2] * inv), (_Float16)(v[3] * inv),
-                                 (_Float16)(v[4] * inv), (_Float16)(v[5] * inv), (_Float16)(v[6] * inv), (_Float16)(v[7] * inv)};
+    const la_f16x8 pf = la_f16x8{(half_t)(v[0] * inv), (half_t)(v[1] * inv), (half_t)(v[2] * inv), (half_t)(v[3] * inv),
+                                 (half_t)(v[4] * inv), (half_t)(v[5] * inv), (half_t)(v[6] * inv), (half_t)(v[7] * inv)};
     __builtin_amdgcn_s_waitcnt(0xc07f);               // the wave's own LDS writes (no other wave touches its region)
     // O^T[hd][query] += V^T P^T
     const int vrow = 4 * lq + (l15 >> 2);
@@ -604,7 +618,7 @@ __global__ __launch_bounds__(256) void local_attention_h_kernel(const _Float16* 
         const la_fp16x4_t t1 = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) la_fp16x4_t*)(sm + ((vbase + 16 * ROWB) ^ (nb << 5))));
         const f16x4 v0 = __builtin_bit_cast(f16x4, t0), v1 = __builtin_bit_cast(f16x4, t1);
         const la_f16x8 vf = la_f16x8{v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-        o[nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pf, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+        o[nb] = GDX_MFMA16(vf, pf, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
     }
     // second rotary at position t+1 (lane: query l15, head-dim 16nb + 4lq + e; partner block nb +- NNB/2), store
     if (active && l15 < window) {
@@ -616,9 +630,9 @@ __global__ __launch_bounds__(256) void local_attention_h_kernel(const _Float16* 
             const f32x4 sn = *reinterpret_cast<const f32x4*>(sinT + (long)pos * HALF + 16 * nb + 4 * lq);
             const f32x4 lo = o[nb], hi = o[nb + NNB / 2];
             const f32x4 rl = lo * c - hi * sn, rh = hi * c + lo * sn;
-            *reinterpret_cast<f16x4*>(enc16 + orow + 16 * nb + 4 * lq) = f16x4{(_Float16)rl[0], (_Float16)rl[1], (_Float16)rl[2], (_Float16)rl[3]};
+            *reinterpret_cast<f16x4*>(enc16 + orow + 16 * nb + 4 * lq) = f16x4{(half_t)rl[0], (half_t)rl[1], (half_t)rl[2], (half_t)rl[3]};
             *reinterpret_cast<f16x4*>(enc16 + orow + 16 * (nb + NNB / 2) + 4 * lq) =
-                f16x4{(_Float16)rh[0], (_Float16)rh[1], (_Float16)rh[2], (_Float16)rh[3]};
+                f16x4{(half_t)rh[0], (half_t)rh[1], (half_t)rh[2], (half_t)rh[3]};
             if (enc32) {
                 *reinterpret_cast<f32x4*>(enc32 + orow + 16 * nb + 4 * lq) = rl;
                 *reinterpret_cast<f32x4*>(enc32 + orow + 16 * (nb + NNB / 2) + 4 * lq) = rh;
@@ -632,8 +646,10 @@ bool local_attention_f16_supported(int d, int heads, int window) {
     return (e == 64 || e == 128) && window >= 1 && window <= 16 && d % 8 == 0;
 }
 
-hipError_t launch_local_attention_f16(const _Float16* xseq, const float* cosT, const float* sinT, _Float16* enc16,
+hipError_t launch_local_attention_f16(const _Float16* xseq_, const float* cosT, const float* sinT, _Float16* enc16_,
                                       float* enc32, int B, int T, int d, int heads, int window, hipStream_t s) {
+    const half_t* xseq = reinterpret_cast<const half_t*>(xseq_);
+    half_t* enc16 = reinterpret_cast<half_t*>(enc16_);
     const int e = d / heads;
     const int nwork = B * heads * (T / window);
     const dim3 grid((nwork + 3) / 4), block(256);
@@ -735,33 +751,36 @@ hipError_t launch_mfcc_cepstrum(const float* mel, int ldm, const float* energy, 
     return hipGetLastError();
 }
 
-__global__ void convert_f16_kernel(const float* __restrict__ src, _Float16* __restrict__ dst, int64_t n) {
+__global__ void convert_f16_kernel(const float* __restrict__ src, half_t* __restrict__ dst, int64_t n) {
     const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
     if (i + 3 < n) {
         const float4 v = *reinterpret_cast<const float4*>(src + i);
-        typedef _Float16 h4 __attribute__((ext_vector_type(4)));
-        *reinterpret_cast<h4*>(dst + i) = h4{(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
+        typedef half_t h4 __attribute__((ext_vector_type(4)));
+        *reinterpret_cast<h4*>(dst + i) = h4{(half_t)v.x, (half_t)v.y, (half_t)v.z, (half_t)v.w};
     } else {
-        for (int64_t k = i; k < n; ++k) dst[k] = (_Float16)src[k];
+        for (int64_t k = i; k < n; ++k) dst[k] = (half_t)src[k];
     }
 }
 
-__global__ void convert_f32_kernel(const _Float16* __restrict__ src, float* __restrict__ dst, int64_t n) {
+__global__ void convert_f32_kernel(const half_t* __restrict__ src, float* __restrict__ dst, int64_t n) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) dst[i] = (float)src[i];
 }
 
-hipError_t launch_convert_f32(const _Float16* src, float* dst, int64_t n, hipStream_t s) {
+hipError_t launch_convert_f32(const _Float16* src_, float* dst, int64_t n, hipStream_t s) {
+    const half_t* src = reinterpret_cast<const half_t*>(src_);
     if (n <= 0) return hipSuccess;
     hipLaunchKernelGGL(convert_f32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, src, dst, n);
     return hipGetLastError();
 }
 
-hipError_t launch_convert_f16(const float* src, _Float16* dst, int64_t n, hipStream_t s) {
+hipError_t launch_convert_f16(const float* src, _Float16* dst_, int64_t n, hipStream_t s) {
+    half_t* dst = reinterpret_cast<half_t*>(dst_);
     if (n <= 0) return hipSuccess;
     const int64_t nth = (n + 3) / 4;
     hipLaunchKernelGGL(convert_f16_kernel, dim3((unsigned)((nth + 255) / 256)), dim3(256), 0, s, src, dst, n);
     return hipGetLastError();
 }
 
+GDX_HNS_END
 }  // namespace gdx

@@ -35,8 +35,9 @@ def f32c(t, what):
     return t.contiguous()
 
 
-# gdx.h GDX_DTYPE_*: "fp32" = exact fp32 MFMA everywhere (default); "fp16" = fp16 GEMM operands, fp32 accumulate
-COMPUTE_DTYPES = {"fp32": 0, "fp16": 1}
+# gdx.h GDX_DTYPE_*: "fp32" = exact fp32 MFMA everywhere (default); "fp16" / "bf16" = 16-bit GEMM / attention operands and
+# activation stream, fp32 accumulate (bf16: fp32's exponent range, 8 significant bits)
+COMPUTE_DTYPES = {"fp32": 0, "fp16": 1, "bf16": 2}
 
 
 class Engine:

@@ -252,7 +252,7 @@ class MDM(_NativeDenoiser):
             raise NotImplementedError("use_text needs CLIP weights (network download); not available")
 
         self.seed_poses = kargs.get("seed_poses", 0)
-        self.compute_dtype = kargs.get("compute_dtype", None)   # additive: "fp32" (default) | "fp16" (engine.COMPUTE_DTYPES)
+        self.compute_dtype = kargs.get("compute_dtype", None)   # additive: "fp32" (default) | "fp16" | "bf16" (engine.COMPUTE_DTYPES)
         if self.seed_poses > 0:
             self.seed_pose_encoder = SeedPoseEncoder(njoints, self.seed_poses, latent_dim)
 

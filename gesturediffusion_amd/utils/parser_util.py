@@ -131,8 +131,9 @@ def add_native_options(parser):
     group.add_argument("--packed_cache", default='', type=str,
                        help="Directory of packed-weight images: the first run of a checkpoint writes the kernels' operand "
                             "layout there, later runs upload it instead of unpickling and repacking the checkpoint.")
-    group.add_argument("--compute_dtype", default='fp32', choices=['fp32', 'fp16'],
-                       help="fp32 = exact fp32 MFMA (reference precision); fp16 = fp16 MFMA operands, fp32 accumulate.")
+    group.add_argument("--compute_dtype", default='fp32', choices=['fp32', 'fp16', 'bf16'],
+                       help="fp32 = exact fp32 MFMA (reference precision); fp16 / bf16 = 16-bit MFMA operands and activation "
+                            "stream, fp32 accumulate (bf16 trades 3 significant bits for fp32's exponent range).")
 
 
 def generate_args(argv=None):

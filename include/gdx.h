@@ -38,8 +38,10 @@ enum { GDX_COND = 0,          /* y without 'uncond'                     (model/m
        GDX_CFG = 2 };         /* both passes + blend                    (model/cfg_sampler.py:23-28) */
 
 enum { GDX_DTYPE_F32 = 0,     /* every GEMM on the exact fp32 MFMA (default; parity tolerance of the fp32 path) */
-       GDX_DTYPE_F16 = 1 };   /* fp16 MFMA operands (weights + activations), fp32 accumulate / residual stream /
-                                 LayerNorm / softmax: BASELINE config 5's reduced-precision mode */
+       GDX_DTYPE_F16 = 1,     /* fp16 MFMA operands (weights + activations), fp32 accumulate / LayerNorm statistics / softmax:
+                                 BASELINE config 5's reduced-precision mode */
+       GDX_DTYPE_BF16 = 2 };  /* the same mode with bf16 elements: fp32's exponent range (fp16 overflows at 65 504) for 8 instead of
+                                 11 significant bits; the same kernels compiled for __bf16 (tolerance 6e-2 instead of 2e-2) */
 
 enum { GDX_SAMPLER_P = 0,     /* p_sample      diffusion/gaussian_diffusion.py:496-548 */
        GDX_SAMPLER_DDIM = 1 };/* ddim_sample   diffusion/gaussian_diffusion.py:732-782 */
@@ -303,6 +305,9 @@ int gdx_linear_f16(const float* A, const float* W, const float* bias, float* C32
  * (csrc/attentionh.hip): qkv [B*S][3d] and ctx [B*S][d] are fp32 device arrays converted to / from
  * fp16 by the call.  head_dim = d / H in {32, 64, 128, 256}.  Synchronises the stream. */
 int gdx_attention_f16(const float* qkv, float* ctx, int32_t B, int32_t S, int32_t H, int32_t d, void* stream);
+/* element type (GDX_DTYPE_F16, the default, or GDX_DTYPE_BF16) of the stand-alone entry points gdx_linear_f16,
+ * gdx_attention_f16, gdx_bench_gemm_f16 and gdx_bench_attention's reduced-precision version; process-wide, tests only */
+int gdx_set_test_half_dtype(int32_t dtype);
 /* ctx = softmax(Q K^T / sqrt(hd)) V per (sample, head) through the fp32 attention kernels: the SDPA inside
  * nn.MultiheadAttention of the encoder layers (model/mdm.py:90-96).  qkv [B*S][3d], ctx [B*S][d] fp32 device arrays.
  * version 0 = the choice gdx_forward makes, 1 = 32x32-block kernel (attention.hip), 2 = attention2.hip,

@@ -298,6 +298,113 @@ def test_inpainting_with_epsilon_raises_like_the_reference():
         df.p_sample_loop(m, tuple(tape[0].shape), noise_tape=tape, model_kwargs={"y": y})
 
 
+# ------------------------------------------------------------------------------------------------ bf16 mode
+BF16_TOL = 6e-2      # bf16 carries 8 significant bits (fp16: 11): the fp16 mode's 2e-2, times 2^3, rounded down
+
+
+def _with_test_dtype(dtype_code, fn):
+    from gesturediffusion_amd import _lib
+    lib = _lib.load()
+    _lib.check(lib.gdx_set_test_half_dtype(dtype_code), lib)
+    try:
+        return fn(lib)
+    finally:
+        _lib.check(lib.gdx_set_test_half_dtype(1), lib)
+
+
+@pytest.mark.parametrize("M,N,K,gelu", [(1000, 1024, 512, 0), (333, 320, 576, 1), (16000, 3072, 256, 1), (66688, 1024, 1024, 0)])
+def test_bf16_gemm_vs_torch(M, N, K, gelu):
+    """csrc/gemmh.hip compiled for __bf16 (gdx::b16): exact products of the bf16-rounded operands, fp32 accumulate -> the
+    fp32 output matches an fp64 reference on the same rounded operands to fp32 round-off, the bf16 output to bf16 round-off
+    (the last shape takes the 256x256 kernel with the row cut)."""
+    import ctypes as C
+    from gesturediffusion_amd import _lib
+    d = dev()
+    g = torch.Generator(device=d).manual_seed(M + N)
+    A = torch.randn(M, K, device=d, generator=g)
+    W = torch.randn(N, K, device=d, generator=g) / K ** 0.5
+    b = torch.randn(N, device=d, generator=g)
+    C32 = torch.full((M, N), float("nan"), device=d)
+    C16 = torch.full((M, N), float("nan"), device=d)
+    vp = lambda t: C.c_void_p(t.data_ptr())   # noqa: E731
+    s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    _with_test_dtype(2, lambda lib: _lib.check(lib.gdx_linear_f16(vp(A), vp(W), vp(b), vp(C32), vp(C16), M, N, K, gelu, s), lib))
+    ref = A.bfloat16().double() @ W.bfloat16().double().t() + b.double()
+    if gelu:
+        ref = torch.nn.functional.gelu(ref)
+    err = lambda c: float(((c.double() - ref).abs().max() / ref.abs().max()).item())   # noqa: E731
+    assert err(C32) < (3e-5 if gelu else 2e-6)
+    assert err(C16) < 8e-3                             # one bf16 rounding of the output: 2^-8
+
+
+@pytest.mark.parametrize("B,S,H,dm", [(2, 197, 4, 512), (1, 521, 4, 1024), (3, 250, 2, 128), (2, 31, 8, 512), (40, 197, 4, 512),
+                                      (33, 100, 4, 1024)])
+def test_bf16_attention_vs_torch(B, S, H, dm):
+    """csrc/attentionh.hip compiled for __bf16 against fp64 softmax attention on the bf16-rounded q/k/v."""
+    import ctypes as C
+    from gesturediffusion_amd import _lib
+    d = dev()
+    hd = dm // H
+    g = torch.Generator(device=d).manual_seed(S)
+    qkv = torch.randn(B * S, 3 * dm, device=d, generator=g)
+    qkv[:, :dm] *= 2.0
+    ctx = torch.full((B * S, dm), float("nan"), device=d)
+    s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    _with_test_dtype(2, lambda lib: _lib.check(lib.gdx_attention_f16(C.c_void_p(qkv.data_ptr()), C.c_void_p(ctx.data_ptr()), B, S, H,
+                                                                     dm, s), lib))
+    r = qkv.bfloat16().double().view(B, S, 3, H, hd)
+    q, k, v = (r[:, :, i].permute(0, 2, 1, 3) for i in range(3))
+    p = torch.softmax(q @ k.transpose(-1, -2) / hd ** 0.5, dim=-1)
+    ref = (p @ v).permute(0, 2, 1, 3).reshape(B * S, dm)
+    assert rel_err(ctx.cpu().double(), ref.cpu()) < 1.6e-2   # probabilities and the output are rounded to bf16 (2^-8 each)
+
+
+@pytest.mark.parametrize("arch", ["mdm", "mdm_old"])
+@pytest.mark.parametrize("name", ["p20", "ddim10_cfg", "p20_cfg_inpaint"])
+def test_bf16_mode_loops_vs_reference_golden(arch, name):
+    """Whole loops of the reference (fp32) against the bf16 mode, fused and step-wise."""
+    from test_gpu_parity import _run_loop_case
+    _run_loop_case(arch, name, True, "bf16", BF16_TOL)
+    _run_loop_case(arch, name, False, "bf16", BF16_TOL)
+
+
+@pytest.mark.parametrize("name,arch,J,dm", [("c1_v2", "mdm", 150, 512), ("c2_v1", "mdm_old", 263, 512), ("c5_v2", "mdm", 498, 1024)])
+def test_bf16_mode_real_shapes_vs_reference_golden(name, arch, J, dm):
+    """BASELINE shapes (8 layers) in the bf16 mode against the reference's fp32 outputs."""
+    from gesturediffusion_amd.utils.init import init_state_dict, synthetic_inputs
+    g = load_golden("real_shapes.npz")
+    B, T = int(g[name + ".meta"][0]), int(g[name + ".meta"][1])
+    cfg = _real_cfg(arch, J, dm)
+    m = build_model(arch, cfg, init_state_dict(cfg, seed=0))
+    m.compute_dtype = "bf16"
+    x, seedp, mfcc = synthetic_inputs(cfg, B, T, seed=10)
+    d = dev()
+    t = torch.from_numpy(g[name + ".t"]).to(d)
+    y = {"seed": seedp.to(d), "mfcc": mfcc.to(d)}
+    e = rel_err(m(x.to(d), t, y).cpu(), g[name + ".out"])
+    assert e < BF16_TOL, (name, e)
+    assert rel_err(m(x.to(d), t, dict(y, uncond=True)).cpu(), g[name + ".out_uncond"]) < BF16_TOL
+
+
+def test_packed_image_bf16_roundtrip_and_dtype_check():
+    from gesturediffusion_amd._lib import GdxError
+    from gesturediffusion_amd.utils.init import init_state_dict
+    cfg = dict(TINY, arch="mdm")
+    a = build_model("mdm", cfg, init_state_dict(cfg, seed=31, perturb=True))
+    b = build_model("mdm", cfg, init_state_dict(cfg, seed=32, perturb=True))
+    out_a = _forward(a, cfg, compute_dtype="bf16")
+    out_h = _forward(build_model("mdm", cfg, init_state_dict(cfg, seed=31, perturb=True)), cfg, compute_dtype="fp16")
+    assert not torch.equal(out_a, out_h) and rel_err(out_a.cpu(), out_h.cpu()) < BF16_TOL
+    blob = a.export_packed(dev())
+    b.compute_dtype = "bf16"
+    b.load_packed(blob, dev())
+    assert torch.equal(_forward(b, cfg), out_a)
+    c = build_model("mdm", cfg, init_state_dict(cfg, seed=33, perturb=True))
+    c.compute_dtype = "fp16"
+    with pytest.raises(GdxError, match="another c"):
+        c.load_packed(blob, dev())
+
+
 # ------------------------------------------------------------------------------------------------ N2: checkpoints
 def test_checkpoint_roundtrip_vs_oracle(tmp_path):
     """a checkpoint written the way the reference's trainer writes it (`train/training_loop.py:265-285`: the
