@@ -1408,6 +1408,26 @@ extern "C" int gdx_bench_attention(int32_t B, int32_t S, int32_t H, int32_t d, i
     *avg_us = ms * 1000.0f / (float)iters;
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
+    if (version == 3 && getenv("GDX_GEMM_DEBUG")) {      // one extra launch with in-kernel stamps (persistent fp16 kernel only)
+        unsigned long long* dd = nullptr;
+        if (!dev_alloc(pool, (void**)&dd, 512)) {
+            (void)hipMemsetAsync(dd, 0, 512, s);
+            g2_dbg_buf = dd;
+            (void)run();
+            g2_dbg_buf = nullptr;
+            unsigned long long hh[16] = {0};
+            (void)hipMemcpyAsync(hh, dd, 128, hipMemcpyDeviceToHost, s);
+            (void)hipStreamSynchronize(s);
+            for (int wv = 0; wv < 2; ++wv) {
+                const unsigned long long* o = hh + 8 * wv;
+                if (o[5])
+                    fprintf(stderr, "[attentionh8p stamps] workgroup 0, wave %d: %llu tiles, kernel %.1f us at %.2f GHz; cycles per tile: DMA issue %.0f, "
+                            "QK^T %.0f, softmax %.0f, PV %.0f, wait + barrier %.0f\n", wv ? 7 : 0, o[5], o[7] / 100.0,
+                            o[7] ? (double)o[6] / (o[7] * 10.0) : 0.0, (double)o[0] / o[5], (double)o[1] / o[5], (double)o[2] / o[5],
+                            (double)o[3] / o[5], (double)o[4] / o[5]);
+            }
+        }
+    }
     free_pool(pool);
     return 0;
 }

@@ -32,6 +32,8 @@
 #endif
 
 namespace gdx {
+int gemm2_num_cus();
+extern unsigned long long* g2_dbg_buf;   // gemm2.hip: set by the bench helpers when GDX_GEMM_DEBUG is set
 GDX_HNS_BEGIN
 
 typedef half_t f16x8 __attribute__((ext_vector_type(8)));
@@ -656,6 +658,272 @@ __global__ __launch_bounds__(512, 1) void attentionh8q_kernel(const _Float16* __
 #endif
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// PERSISTENT form of the kernel above: one workgroup per CU walks the work items (sample, head, query chunk) w = block,
+// block + G, ...  The kernel above keeps one workgroup per CU resident (128 KiB of LDS, 8 x 256 registers), so between two
+// of them nothing overlaps: every item pays its ring fill (three 32-KiB tiles from L2), its Q loads and its output stores
+// with the matrix pipe idle.  Here the K/V stream simply runs on into the next item's tiles while the current item's last
+// tiles are being multiplied (the ring and its stage counters never restart), and the output stores of an item drain under
+// the next item's first tiles.  The counted vmcnt waits stay valid with the extra Q loads / stores in the queue: memory
+// operations retire in order, so "all but the youngest N" can only cover MORE than the tile it is meant to cover.  Per item
+// the arithmetic is the kernel above's, statement for statement (same tile order, same online-softmax state): bit-identical.
+template <int HD, int QB, bool DBG>
+__global__ __launch_bounds__(512, 1) void attentionh8p_kernel(const _Float16* __restrict__ qkv, _Float16* __restrict__ ctx,
+                                                              int S, int H, int d, int nchunk, int nitems, float c_log2,
+                                                              long qkv_bytes, unsigned long long* dbg) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    constexpr int ROWB = HD * 2, CPR = ROWB / 16, T_BYTES = 32 * ROWB, STAGE_BYTES = 2 * T_BYTES;
+    constexpr int T_P = T_BYTES / 1024, P = 2 * T_P, PW = (P + 7) / 8;
+    constexpr int NST = 4;
+    constexpr int NKS = HD / 32, NNB = HD / 16;
+    constexpr float RESCALE_THR = 8.0f;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid) >> 6;
+    const int l15 = lane & 15, lq = lane >> 4;
+    const long ld = 3L * d;
+    const int nqb = (S + 15) / 16;
+    const int ntiles = (S + 31) / 32;
+    const int G = gridDim.x;
+    const int my_items = (int)blockIdx.x < nitems ? (nitems - (int)blockIdx.x + G - 1) / G : 0;
+    if (my_items == 0) return;
+    auto fswz = [](int row) { return HD == 32 ? ((row >> 2) & 1) << 1 : HD == 64 ? ((row >> 1) & 3) << 1 : (row & 7) << 1; };
+    // item i of this workgroup -> element offset of its (sample, head) inside qkv
+    auto item_off = [&](int i) -> long {
+        const int w = (int)blockIdx.x + (i < my_items ? i : my_items - 1) * G;    // past the end: harmless re-reads of the last item
+        const int hh = (w / nchunk) % H, bb = w / (nchunk * H);
+        return (long)bb * S * ld + hh * HD;
+    };
+
+    // ---- the K/V stream: tile ld_kt of stream item ld_it goes to ring stage wst; it runs NST - 1 tiles ahead of the MFMAs
+    int voff[PW];
+#pragma unroll
+    for (int i = 0; i < PW; ++i) {
+        int piece = wave + 8 * i;
+        piece = piece < P ? piece : P - 1;
+        const int pl = piece < T_P ? piece : piece - T_P;
+        const int row = pl * (1024 / ROWB) + lane / CPR;
+        voff[i] = (int)(row * ld * 2) + (((lane % CPR) ^ fswz(row)) * 16);
+    }
+    int ld_it = 0, ld_kt = 0;
+    long st_off = item_off(0);
+    auto issue = [&](int stage) {
+        const long kb_off = (st_off + d) * 2, vb_off = (st_off + 2 * d) * 2;
+        const auto rsrcK = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(qkv + st_off + d), (short)0, ah_records(qkv_bytes - kb_off), 0x00020000);
+        const auto rsrcV = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(qkv + st_off + 2 * d), (short)0, ah_records(qkv_bytes - vb_off), 0x00020000);
+        const int so = (int)((long)ld_kt * 32 * ld * 2);
+        char* sb = smem + stage * STAGE_BYTES;
+#pragma unroll
+        for (int i = 0; i < PW; ++i) {
+            int piece = wave + 8 * i;
+            piece = piece < P ? piece : P - 1;
+            if (piece < T_P)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcK, (lds_ptr_t)(sb + piece * 1024), 16, voff[i], so, 0, 0);
+            else
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcV, (lds_ptr_t)(sb + T_BYTES + (piece - T_P) * 1024), 16, voff[i], so, 0, 0);
+        }
+        if (++ld_kt == ntiles) {                                      // on into the next item's tiles
+            ld_kt = 0;
+            ++ld_it;
+            st_off = item_off(ld_it);
+        }
+    };
+    const int kbase = l15 * ROWB + ((lq ^ fswz(l15)) << 4);
+    const int vrow = 4 * lq + (l15 >> 2);
+    const int vbase = T_BYTES + vrow * ROWB + ((fswz(vrow) >> 1) << 5) + (l15 & 3) * 8;
+
+#pragma unroll
+    for (int s = 0; s < NST - 1; ++s) issue(s);
+    ah_wait_vm<(NST - 2) * PW>();
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    int stage = 0, wst = NST - 1;
+    // diagnostic stamps (GDX_GEMM_DEBUG only; waves 0 and 7 of workgroup 0): cycles per tile spent issuing the DMA pieces, in
+    // QK^T, in the softmax, in PV and in the wait + barrier
+    unsigned long long d_is = 0, d_qk = 0, d_sm = 0, d_pv = 0, d_bar = 0, n_t = 0, t_a = 0, t_b = 0;
+    const unsigned long long tk0 = DBG ? __builtin_amdgcn_s_memtime() : 0, tr0 = DBG ? __builtin_amdgcn_s_memrealtime() : 0;
+
+    for (int it = 0; it < my_items; ++it) {
+        const int w = (int)blockIdx.x + it * G;
+        const int ci = w % nchunk;
+        const int h = (w / nchunk) % H, b = w / (nchunk * H);
+        const long base_off = (long)b * S * ld + h * HD;
+        const _Float16* base = qkv + base_off;
+        const int qb_lo = (int)((long)ci * nqb / nchunk), qb_hi = (int)((long)(ci + 1) * nqb / nchunk);
+        const int nblk = qb_hi - qb_lo;                                   // <= 8 * QB
+        const int mine = wave < nblk ? min((nblk - wave + 7) / 8, QB) : 0;   // blocks qb_lo + wave + 8*qi
+
+        f16x8 qf[QB][NKS];
+#pragma unroll
+        for (int qi = 0; qi < QB; ++qi) {
+            int q = 16 * (qb_lo + wave + 8 * qi) + l15;
+            q = q < S ? q : S - 1;
+            const _Float16* qp = base + (long)q * ld + 8 * lq;
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks) qf[qi][ks] = *reinterpret_cast<const f16x8*>(qp + 32 * ks);
+        }
+        f32x4 o[QB][NNB];
+        float m_run[QB], l_run[QB];
+#pragma unroll
+        for (int qi = 0; qi < QB; ++qi) {
+#pragma unroll
+            for (int nb = 0; nb < NNB; ++nb) o[qi][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+            m_run[qi] = -INFINITY;
+            l_run[qi] = 0.0f;
+        }
+        auto run_tiles = [&](auto nq_tag) {
+            constexpr int NQ = decltype(nq_tag)::value;
+            for (int kt = 0; kt < ntiles; ++kt) {
+                const char* St = smem + stage * STAGE_BYTES;
+                if constexpr (DBG) { __builtin_amdgcn_sched_barrier(0); t_a = __builtin_amdgcn_s_memtime(); }
+                issue(wst);
+                wst = wst == NST - 1 ? 0 : wst + 1;
+                if constexpr (DBG) { __builtin_amdgcn_sched_barrier(0); t_b = __builtin_amdgcn_s_memtime(); d_is += t_b - t_a; t_a = t_b; }
+                if constexpr (NQ > 0) {
+                    f32x4 s[QB][2];
+#pragma unroll
+                    for (int qi = 0; qi < QB; ++qi) s[qi][0] = s[qi][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    constexpr int NR = 2 * NKS, PD = NR < 4 ? NR - 1 : 3;
+                    auto kread = [&](int r) {
+                        return *reinterpret_cast<const f16x8*>(St + ((kbase + (r / NKS) * 16 * ROWB) ^ ((r % NKS) << 6)));
+                    };
+                    f16x8 kring[PD + 1];
+#pragma unroll
+                    for (int r = 0; r < PD; ++r) kring[r] = kread(r);
+#pragma unroll
+                    for (int r = 0; r < NR; ++r) {
+                        if (r + PD < NR) kring[(r + PD) % (PD + 1)] = kread(r + PD);
+#pragma unroll
+                        for (int qi = 0; qi < NQ; ++qi)
+                            s[qi][r / NKS] = GDX_MFMA16(kring[r % (PD + 1)], qf[qi][r % NKS], s[qi][r / NKS], 0, 0, 0);
+                    }
+                    if constexpr (DBG) { __builtin_amdgcn_sched_barrier(0); t_b = __builtin_amdgcn_s_memtime(); d_qk += t_b - t_a; t_a = t_b; }
+                    constexpr int VD = NNB < 4 ? NNB - 1 : 3;
+                    auto vread = [&](int nb, int half) { return lds_read_tr(St + ((vbase + half * 16 * ROWB) ^ (nb << 5))); };
+                    f16x4 vring[VD + 1][2];
+#pragma unroll
+                    for (int nb = 0; nb < VD; ++nb) {
+                        vring[nb][0] = vread(nb, 0);
+                        vring[nb][1] = vread(nb, 1);
+                    }
+                    f16x8 pf[QB];
+                    const bool tail = kt * 32 + 32 > S;
+#pragma unroll
+                    for (int qi = 0; qi < NQ; ++qi) {
+                        float v[8];
+#pragma unroll
+                        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[kb * 4 + e] = s[qi][kb][e];
+                        if (tail) {
+#pragma unroll
+                            for (int j = 0; j < 8; ++j)
+                                if (kt * 32 + (j >> 2) * 16 + 4 * lq + (j & 3) >= S) v[j] = -INFINITY;
+                        }
+                        float mx = fmaxf(fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3])), fmaxf(fmaxf(v[4], v[5]), fmaxf(v[6], v[7]))) * c_log2;
+                        if (__any(mx > m_run[qi] + RESCALE_THR)) {
+                            mx = fmaxf(mx, __shfl_xor(mx, 16));
+                            mx = fmaxf(mx, __shfl_xor(mx, 32));
+                            const float m_new = fmaxf(m_run[qi], mx);
+                            const float alpha = __builtin_amdgcn_exp2f(m_run[qi] - m_new);
+                            l_run[qi] *= alpha;
+#pragma unroll
+                            for (int nb = 0; nb < NNB; ++nb) o[qi][nb] *= alpha;
+                            m_run[qi] = m_new;
+                        }
+                        float psum = 0.0f;
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) {
+                            v[j] = __builtin_amdgcn_exp2f(fmaf(v[j], c_log2, -m_run[qi]));
+                            psum += v[j];
+                        }
+                        l_run[qi] += psum;
+                        pf[qi] = f16x8{(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3],
+                                       (half_t)v[4], (half_t)v[5], (half_t)v[6], (half_t)v[7]};
+                    }
+                    if constexpr (DBG) { __builtin_amdgcn_sched_barrier(0); t_b = __builtin_amdgcn_s_memtime(); d_sm += t_b - t_a; t_a = t_b; }
+#pragma unroll
+                    for (int nb = 0; nb < NNB; ++nb) {
+                        if (nb + VD < NNB) {
+                            vring[(nb + VD) % (VD + 1)][0] = vread(nb + VD, 0);
+                            vring[(nb + VD) % (VD + 1)][1] = vread(nb + VD, 1);
+                        }
+                        const f16x4 v0 = vring[nb % (VD + 1)][0], v1 = vring[nb % (VD + 1)][1];
+                        const f16x8 vf = f16x8{v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+#pragma unroll
+                        for (int qi = 0; qi < NQ; ++qi)
+                            o[qi][nb] = GDX_MFMA16(vf, pf[qi], o[qi][nb], 0, 0, 0);
+                    }
+                }
+                if constexpr (DBG) { __builtin_amdgcn_sched_barrier(0); t_b = __builtin_amdgcn_s_memtime(); d_pv += t_b - t_a; t_a = t_b; }
+                ah_wait_vm<(NST - 2) * PW>();
+                __builtin_amdgcn_s_waitcnt(0xc07f);
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+                stage = stage == NST - 1 ? 0 : stage + 1;
+                if constexpr (DBG) { __builtin_amdgcn_sched_barrier(0); t_b = __builtin_amdgcn_s_memtime(); d_bar += t_b - t_a; ++n_t; }
+            }
+        };
+        if (mine == 2) run_tiles(std::integral_constant<int, 2>{});
+        else if (mine == 1) run_tiles(std::integral_constant<int, 1>{});
+        else run_tiles(std::integral_constant<int, 0>{});
+#pragma unroll
+        for (int qi = 0; qi < QB; ++qi) {
+            if (qi >= mine) continue;
+            float l_tot = l_run[qi];
+            l_tot += __shfl_xor(l_tot, 16);
+            l_tot += __shfl_xor(l_tot, 32);
+            const float inv = 1.0f / l_tot;
+            const int q = 16 * (qb_lo + wave + 8 * qi) + l15;
+            if (q < S) {
+                _Float16* op = ctx + ((long)b * S + q) * d + h * HD + 4 * lq;
+#pragma unroll
+                for (int nb = 0; nb < NNB; ++nb) {
+                    const f32x4 r = o[qi][nb] * inv;
+                    *reinterpret_cast<f16x4*>(op + 16 * nb) = f16x4{(half_t)r[0], (half_t)r[1], (half_t)r[2], (half_t)r[3]};
+                }
+            }
+        }
+    }
+    if (DBG && dbg && blockIdx.x == 0 && lane == 0 && (wave == 0 || wave == 7)) {
+        unsigned long long* o = dbg + (wave == 0 ? 0 : 8);
+        o[0] = d_is; o[1] = d_qk; o[2] = d_sm; o[3] = d_pv; o[4] = d_bar; o[5] = n_t;
+        o[6] = __builtin_amdgcn_s_memtime() - tk0; o[7] = __builtin_amdgcn_s_memrealtime() - tr0;
+    }
+    ah_wait_vm<0>();
+#endif
+}
+
+template <int HD>
+static hipError_t launch_ah8p(const _Float16* qkv, _Float16* ctx, int B, int S, int H, int d, long qkv_bytes, int num_cus,
+                              hipStream_t s) {
+    const size_t lds = (size_t)4 * 2 * 32 * HD * 2;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attentionh8p_kernel<HD, 2, false>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attentionh8p_kernel<HD, 2, true>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr_done = true;
+    }
+    const int nqb = (S + 15) / 16;
+    const int nchunk = (nqb + 15) / 16;
+    const int nitems = B * H * nchunk;
+    const int grid = nitems < num_cus ? nitems : num_cus;
+    const float c_log2 = 1.4426950408889634f / sqrtf((float)HD);
+    if (g2_dbg_buf)                                               // the stamped build of the kernel (diagnostic launches only)
+        hipLaunchKernelGGL((attentionh8p_kernel<HD, 2, true>), dim3(grid), dim3(512), lds, s, qkv, ctx, S, H, d, nchunk, nitems,
+                           c_log2, qkv_bytes, g2_dbg_buf);
+    else
+        hipLaunchKernelGGL((attentionh8p_kernel<HD, 2, false>), dim3(grid), dim3(512), lds, s, qkv, ctx, S, H, d, nchunk, nitems,
+                           c_log2, qkv_bytes, g2_dbg_buf);
+    return hipGetLastError();
+}
+
 template <int HD>
 static hipError_t launch_ah8q(const _Float16* qkv, _Float16* ctx, int B, int S, int H, int d, long qkv_bytes, hipStream_t s) {
     const size_t lds = (size_t)4 * 2 * 32 * HD * 2;
@@ -722,9 +990,18 @@ hipError_t launch_attentionh(const _Float16* qkv, _Float16* ctx, int B, int S, i
     // measured (tools/attnh_one.py, us): B=128 S=521 hd=256: 4+4 waves 318, 8 waves x 1 block 373, 8 waves x 2 blocks 292;
     // B=16 (config 5's per-GPU share): 49.5 / 58.9 / 37.4;  B=64 S=197 hd=128: 23.3 / 19.9 / 18.7.  The 8 x 2 kernel needs
     // enough workgroups to fill the chip (it makes half as many), so small problems keep the older choices.
-    static const char* force = getenv("GDX_ATTNH_WAVES");            // A/B switch: "4", "8" or "q" (8 waves x 2 blocks)
+    static const char* force = getenv("GDX_ATTNH_WAVES");            // A/B switch: "4", "8", "q" (8 waves x 2 blocks) or "p" (persistent)
     const int nqb = (S + 15) / 16;
-    const bool useq = force ? force[0] == 'q' : (hd >= 64 && (long)B * H * ((nqb + 15) / 16) >= 128);
+    const long nitems = (long)B * H * ((nqb + 15) / 16);
+    const int num_cus = gemm2_num_cus();
+    // persistent form once every CU has at least two items to chain (measured: tools/ab_attnp.sh, profiles/r02h_*)
+    const bool usep = force ? force[0] == 'p' : (hd >= 64 && nitems >= 2L * num_cus);
+    if (usep) {
+        if (hd == 256) return launch_ah8p<256>(qkv, ctx, B, S, H, d, bytes, num_cus, s);
+        if (hd == 128) return launch_ah8p<128>(qkv, ctx, B, S, H, d, bytes, num_cus, s);
+        if (hd == 64) return launch_ah8p<64>(qkv, ctx, B, S, H, d, bytes, num_cus, s);
+    }
+    const bool useq = force ? force[0] == 'q' : (hd >= 64 && nitems >= 128);
     if (useq) {
         if (hd == 256) return launch_ah8q<256>(qkv, ctx, B, S, H, d, bytes, s);
         if (hd == 128) return launch_ah8q<128>(qkv, ctx, B, S, H, d, bytes, s);
