@@ -287,7 +287,8 @@ def main():
         gemm_flops = 2.0 * rows * d * ff
         f16 = p["dtype"] in ("fp16", "bf16")
         traffic, traffic_src = None, None
-        if os.path.exists(TRAFFIC_FILE) and not custom:
+        # the PMC passes were taken at the preset's one-GPU shape: a global batch split over several ranks is another GEMM
+        if os.path.exists(TRAFFIC_FILE) and not custom and not (p["global_batch"] and world > 1):
             ent = json.load(open(TRAFFIC_FILE)).get(args.config)     # PMC passes cannot run inside this process
             if ent:
                 traffic, traffic_src = ent["hbm_bytes_per_launch"], ent["source"]

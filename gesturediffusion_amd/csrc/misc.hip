@@ -350,28 +350,44 @@ hipError_t launch_gather_rows(const float* table, const int64_t* idx, float* out
 // MFCC channels onto the pose channels before InputProcess; V2: model/mdm.py:151-169 feeds them to
 // project_to_lat).  Computed once per conditioning, not once per step:
 //   out[b,t,n] = sum_c mfcc[b,c,t] * W[n][c] + bias[n] (+ pe[t+1][n])
+// One thread owns output column n for a run of ROWS (sample, frame) rows: its C <= 32 weights W[n][0..C) sit in registers
+// (read once, as one contiguous run per thread), a row's C MFCC values are wave-uniform (scalar loads) and the stores are
+// coalesced along n.  (The first version recomputed everything per output element: every thread re-read its weight row
+// with a 128-byte stride for each of its outputs -- 6.5 ms at config 5 against 0.2 ms for this one; same fmaf chain, c
+// ascending, so the results are bit-identical.)
 __global__ __launch_bounds__(256) void mfcc_project_kernel(const float* __restrict__ mfcc, const float* __restrict__ W,
                                                            int ldw, const float* __restrict__ bias,
                                                            const float* __restrict__ pe, float* __restrict__ out,
-                                                           int B, int Bmod, int C, int T, int d, int rps, int off) {
-    const long i = (long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= (long)B * T * d) return;
-    const int n = i % d;
-    const long bt = i / d;
-    const int t = bt % T, b = bt / T;
-    const int bs = b % Bmod;
-    float s = 0.0f;
-    for (int c = 0; c < C; ++c) s = fmaf(mfcc[((long)bs * C + c) * T + t], W[(long)n * ldw + c], s);
-    s += bias[n];
-    if (pe) s += pe[(long)(t + 1) * d + n];
-    out[((long)b * rps + t + off) * d + n] = s;
+                                                           int B, int Bmod, int C, int T, int d, int rps, int off, int rows_per_block) {
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    const long row0 = (long)blockIdx.y * rows_per_block;
+    const long nrows = (long)B * T;
+    if (n >= d) return;
+    float w[32];
+#pragma unroll
+    for (int c = 0; c < 32; ++c) w[c] = c < C ? W[(long)n * ldw + c] : 0.0f;
+    const float bn = bias[n];
+    for (long bt = row0; bt < row0 + rows_per_block && bt < nrows; ++bt) {
+        const int t = bt % T, b = bt / T;
+        const float* m = mfcc + ((long)(b % Bmod) * C) * T + t;
+        float s = 0.0f;
+#pragma unroll
+        for (int c = 0; c < 32; ++c)
+            if (c < C) s = fmaf(m[(long)c * T], w[c], s);
+        s += bn;
+        if (pe) s += pe[(long)(t + 1) * d + n];
+        out[((long)b * rps + t + off) * d + n] = s;
+    }
 }
 
 hipError_t launch_mfcc_project(const float* mfcc, const float* W, int ldw, const float* bias, const float* pe,
                                float* out, int B, int Bmod, int C, int T, int d, int rps, int off, hipStream_t s) {
-    const long n = (long)B * T * d;
-    hipLaunchKernelGGL(mfcc_project_kernel, dim3((n + 255) / 256), dim3(256), 0, s, mfcc, W, ldw, bias, pe, out, B,
-                       Bmod, C, T, d, rps, off);
+    if (C > 32) return hipErrorInvalidValue;                      // gdx_create caps mfcc_dim at 32
+    const long nrows = (long)B * T;
+    if (nrows <= 0) return hipSuccess;
+    const int rpb = 64;
+    hipLaunchKernelGGL(mfcc_project_kernel, dim3((d + 255) / 256, (unsigned)((nrows + rpb - 1) / rpb)), dim3(256), 0, s, mfcc, W,
+                       ldw, bias, pe, out, B, Bmod, C, T, d, rps, off, rpb);
     return hipGetLastError();
 }
 
