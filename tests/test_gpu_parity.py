@@ -448,10 +448,13 @@ def test_fp16_gemm_vs_torch(M, N, K, gelu):
 
 
 @pytest.mark.parametrize("B,S,H,dm", [(2, 197, 4, 512), (1, 521, 4, 1024), (3, 250, 2, 128), (2, 31, 8, 512), (2, 1, 4, 512),
-                                      (1, 300, 4, 256), (2, 77, 4, 128), (40, 197, 4, 512), (33, 100, 4, 1024), (20, 130, 8, 512)])
+                                      (1, 300, 4, 256), (2, 77, 4, 128), (40, 197, 4, 512), (33, 100, 4, 1024), (20, 130, 8, 512),
+                                      (130, 100, 4, 512), (64, 300, 8, 512), (44, 521, 4, 1024)])
 def test_fp16_attention_vs_torch(B, S, H, dm):
-    """csrc/attentionh.hip (head_dim 32/64/128/256, ragged sequence lengths, single token; the last three shapes have
-    enough workgroups to take the 8-wave x 2-block kernel) against fp64 softmax attention on the fp16-rounded q/k/v."""
+    """csrc/attentionh.hip (head_dim 32/64/128/256, ragged sequence lengths, single token; shapes 8-10 have enough
+    workgroups to take the 8-wave x 2-block kernel, the last three at least two work items per CU: the persistent form,
+    head_dim 128 / 64 / 256, one / two / three query chunks per (sample, head)) against fp64 softmax attention on the
+    fp16-rounded q/k/v."""
     import ctypes as C
     from gesturediffusion_amd import _lib
     lib = _lib.load()
