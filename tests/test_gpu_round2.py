@@ -299,7 +299,7 @@ def test_inpainting_with_epsilon_raises_like_the_reference():
 
 
 # ------------------------------------------------------------------------------------------------ bf16 mode
-BF16_TOL = 6e-2      # bf16 carries 8 significant bits (fp16: 11): the fp16 mode's 2e-2, times 2^3, rounded down
+BF16_TOL = 2e-2      # the fp16 / bf16 mode's stated tolerance (measured: forwards 7.6-9.0e-3, loops 5e-3 - 1.2e-2)
 
 
 def _with_test_dtype(dtype_code, fn):
