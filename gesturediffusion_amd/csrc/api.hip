@@ -78,6 +78,9 @@ struct Layer {
 using namespace gdx;
 namespace gdx { extern unsigned long long* g2_dbg_buf; }
 int gdx_sampler_update_state_(const gdx_update_args_t* a, const int* state, long noise_stride, void* stream);   // sampler.hip
+int gdx_sampler_update_tm_(int kind, int B, int J, int T, int ldx, int ldo, const float* coef, int step_index, float* xt,
+                           const float* x0t, const float* scale, int const_noise, uint64_t seed, uint64_t sample_offset,
+                           uint32_t rng_step, int clip, float* out_pose, void* stream);                                  // sampler.hip
 
 struct gdx_model {
     gdx_config_t cfg;
@@ -711,8 +714,10 @@ static int forward_core_f16(gdx_model* h, const float* x, const float* temb, int
 // sample in gdx_forward, once per kept step in gdx_sample_loop, hence the same bits on both sides of the seam.
 // state != nullptr (graph replay, gdx_sample_loop): temb / c2t are the BASES of the loop's tables and the row index is
 // read from device memory (state[0]) by the conditioning-token kernel.
+// tm (gdx_sample_loop's token-major fast path): the pose operand is already in h->xt and the prediction is left in h->x0t,
+// both token-major -- neither transpose runs (x / x0_out unused).
 static int forward_core(gdx_model* h, const float* x, const float* temb, int tstride, const float* c2t, int mode,
-                        float* x0_out, hipStream_t s, const int* state = nullptr) {
+                        float* x0_out, hipStream_t s, const int* state = nullptr, bool tm = false) {
     if (h->f16) return forward_core_f16(h, x, temb, tstride, c2t, mode, x0_out, s, state);
     const int B = h->B, T = h->T, S = h->S, d = h->d, J = h->J;
     const int Beff = mode == GDX_CFG ? 2 * B : B;
@@ -721,7 +726,7 @@ static int forward_core(gdx_model* h, const float* x, const float* temb, int tst
     GemmParams p;
     // pose tensor [B, J, 1, T] -> token-major [Beff*T, Jpad] once (CFG: the same x feeds both halves)
     const int Jp = h->in_x.kpad;
-    HIPCHK(launch_transpose_in(x, h->xt, Beff, B, J, T, Jp, s));
+    if (!tm) HIPCHK(launch_transpose_in(x, h->xt, Beff, B, J, T, Jp, s));
     if (h->cfg.arch == GDX_ARCH_MDM_OLD) {
         HIPCHK(launch_token0(temb, tstride, seed_emb, h->pe, h->xa, nullptr, nullptr, nullptr, nullptr, state, Beff, B, S, d, s));
         // frames -> rows (b, t+1) of the encoder input, + hoisted MFCC/bias/PE term      (model/mdm_old.py:104-112)
@@ -779,7 +784,7 @@ static int forward_core(gdx_model* h, const float* x, const float* temb, int tst
     // OutputProcess (model/mdm.py:372-380): token-major GEMM, then the permute back to [B, J, 1, T]
     p = GemmParams{h->xc, d, h->outp.w, h->outp.kpad, h->outp.bias, nullptr, 0, nullptr, 0, h->x0t, h->ldo, Beff * T, h->ldo, d, T, B};
     if (gemm(A_ROWS, B_WEIGHT, OUT_ROWS, EPI_BIAS, p, s)) return -1;
-    HIPCHK(launch_transpose_out(h->x0t, x0_out, Beff, J, T, h->ldo, s));
+    if (!tm) HIPCHK(launch_transpose_out(h->x0t, x0_out, Beff, J, T, h->ldo, s));
     return 0;
 }
 
@@ -986,6 +991,26 @@ extern "C" int gdx_sample_loop(gdx_handle_t h, const gdx_loop_args_t* a, void* s
     // ~65 small kernels of a step are bound by their GPU-side dispatch + ramp, not by host launch time, and a graph
     // node costs slightly more than a stream launch; so it is OFF by default and kept as a switch.
     const int last_idx = a->run_steps > 0 && a->run_steps <= a->first_index ? a->first_index - a->run_steps + 1 : 0;
+    // Token-major fast path (sampler.hip, update_tm_kernel): with in-kernel Philox noise and nothing else that lives in the
+    // reference layout (no noise tape, inpainting, dumps), the state stays in the input GEMM's operand layout for the whole
+    // call -- one transpose in front, none per step (2 launches and ~40 MB per step less), the last update also writes the
+    // sample in the reference layout.  Bit-identical to the general path (tests: fused Philox loop == step-wise Philox loop).
+    static const bool no_tm = getenv("GDX_LOOP_NO_TM") != nullptr;           // A/B switch
+    if (!no_tm && !h->f16 && !a->noise_tape && !a->inpaint_mask && !a->n_dump && !h->graph_replay && !h->keep_taps && h->T % 4 == 0) {
+        const int Beff = a->mode == GDX_CFG ? 2 * B : B;
+        HIPCHK(launch_transpose_in(a->x, h->xt, Beff, B, h->J, h->T, h->in_x.kpad, s));
+        int k = a->k_base;
+        for (int idx = a->first_index; idx >= last_idx; --idx, ++k) {
+            if (forward_core(h, nullptr, table + (size_t)idx * d, 0, h->c2t_table ? h->c2t_table + (size_t)idx * d : nullptr, a->mode,
+                             nullptr, s, nullptr, true))
+                return -1;
+            if (gdx_sampler_update_tm_(a->kind, B, h->J, h->T, h->in_x.kpad, h->ldo, a->coef, idx, h->xt, h->x0t,
+                                       a->mode == GDX_CFG ? a->scale : nullptr, a->const_noise, a->philox_seed, a->sample_offset,
+                                       (uint32_t)(k + 1), a->clip_denoised, idx == last_idx ? a->x : nullptr, stream))
+                return -1;
+        }
+        return 0;
+    }
     const bool want_graph = h->graph_replay && !h->prof && !h->keep_taps && !a->n_dump && a->first_index - last_idx >= 8;
     int idx = a->first_index, k = a->k_base;
     if (want_graph) {

@@ -151,6 +151,98 @@ __global__ __launch_bounds__(256) void update_kernel(const UpdateDev a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// The same update on a TOKEN-MAJOR loop state (gdx_sample_loop's fast path: in-kernel Philox noise, no inpainting, no
+// dumps, T % 4 == 0).  Between two steps the pose tensor only ever feeds the input GEMM, which wants it token-major
+// ([Beff*T][ldx], row = b*T + t), and the denoiser's output leaves the output GEMM token-major ([Beff*T][ldo]); kept in
+// the reference's [B, J, 1, T] layout it is transposed twice per step for nothing.  Here the state IS the token-major
+// operand: this kernel reads x_t and x0 (cond / uncond halves) token-major and writes x_{t-1} token-major in place
+// (both halves under guidance: the same x feeds both passes), plus, on the last step, the sample in the reference
+// layout.  A thread owns a 4 (frames) x 4 (channels) micro-tile: for channel j the four frames t0..t0+3 are exactly
+// Philox group j*T/4 + t0/4 of the pose-layout numbering, so every element gets the very noise value -- and, through
+// update_value(), the very arithmetic -- of update_kernel: the two paths are bit-identical.
+struct UpdateTmDev {
+    int kind, B, J, T, ldx, ldo;
+    const float* coef; int step_index;
+    float* xt;              // [Beff*T][ldx] in / out
+    const float* x0t;       // [Beff*T][ldo]
+    const float* scale;     // [B] or nullptr: guidance on (Beff = 2B)
+    int const_noise;
+    uint64_t seed, sample_offset;
+    uint32_t rng_step;
+    int clip;
+    float* out_pose;        // [B][J][T] or nullptr (last step)
+};
+
+__device__ __forceinline__ float update_value(int kind, const float* c, float x, float x0, float z) {
+    if (kind == GDX_SAMPLER_P) {
+        const float mean = __fadd_rn(__fmul_rn(c[0], x0), __fmul_rn(c[1], x));
+        return __fadd_rn(mean, __fmul_rn(c[2], z));
+    }
+    const float eps = __fdiv_rn(__fsub_rn(__fmul_rn(c[0], x), x0), c[1]);
+    const float mean = __fadd_rn(__fmul_rn(x0, c[2]), __fmul_rn(c[3], eps));
+    return __fadd_rn(mean, __fmul_rn(c[4], z));
+}
+
+__global__ __launch_bounds__(256) void update_tm_kernel(const UpdateTmDev a) {
+    const int jq_n = (a.J + 3) / 4, tq_n = a.T / 4;
+    const long gid = (long)blockIdx.x * 256 + threadIdx.x;
+    if (gid >= (long)a.B * tq_n * jq_n) return;
+    const int jq = gid % jq_n;
+    const long bt = gid / jq_n;
+    const int tq = bt % tq_n, b = bt / tq_n;
+    const int j0 = 4 * jq, t0 = 4 * tq;
+    const float* c = a.coef + (long)a.step_index * 8;
+    const long row0 = (long)b * a.T + t0;                        // first of the tile's four token rows
+    const long urow = (long)a.B * a.T;                           // offset of the uncond half (guidance)
+    f32x4 x[4], x0[4];                                           // [frame][channel]
+#pragma unroll
+    for (int tt = 0; tt < 4; ++tt) {
+        x[tt] = *reinterpret_cast<const f32x4*>(a.xt + (row0 + tt) * a.ldx + j0);
+        x0[tt] = *reinterpret_cast<const f32x4*>(a.x0t + (row0 + tt) * a.ldo + j0);
+    }
+    if (a.scale) {
+        const float sc = a.scale[b];
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt) {
+            const f32x4 u = *reinterpret_cast<const f32x4*>(a.x0t + (urow + row0 + tt) * a.ldo + j0);
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) x0[tt][jj] = __fadd_rn(u[jj], __fmul_rn(sc, __fsub_rn(x0[tt][jj], u[jj])));
+        }
+    }
+    if (a.clip) {
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) x0[tt][jj] = x0[tt][jj] < -1.0f ? -1.0f : (x0[tt][jj] > 1.0f ? 1.0f : x0[tt][jj]);
+    }
+    const uint64_t sample = a.const_noise ? 0ull : a.sample_offset + (uint64_t)b;
+    f32x4 r[4];
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+        const int j = j0 + jj;
+        if (j < a.J) {
+            const f32x4 z = philox_normal4(a.seed, sample, a.rng_step, (uint32_t)(j * tq_n + tq));   // frames t0 .. t0+3 of channel j
+#pragma unroll
+            for (int tt = 0; tt < 4; ++tt) r[tt][jj] = update_value(a.kind, c, x[tt][jj], x0[tt][jj], z[tt]);
+        } else {
+#pragma unroll
+            for (int tt = 0; tt < 4; ++tt) r[tt][jj] = 0.0f;                                   // K padding of the input GEMM's operand
+        }
+    }
+#pragma unroll
+    for (int tt = 0; tt < 4; ++tt) {
+        *reinterpret_cast<f32x4*>(a.xt + (row0 + tt) * a.ldx + j0) = r[tt];
+        if (a.scale) *reinterpret_cast<f32x4*>(a.xt + (urow + row0 + tt) * a.ldx + j0) = r[tt];
+    }
+    if (a.out_pose) {
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj)
+            if (j0 + jj < a.J)
+                *reinterpret_cast<f32x4*>(a.out_pose + ((long)b * a.J + j0 + jj) * a.T + t0) = f32x4{r[0][jj], r[1][jj], r[2][jj], r[3][jj]};
+    }
+}
+
 __global__ void q_sample_kernel(const float* __restrict__ xs, const float* __restrict__ nz, const float* coef,
                                 int idx, const int64_t* __restrict__ t, long per_sample, long n, float* __restrict__ out) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -307,6 +399,20 @@ hipError_t launch_advance_state(int* st, hipStream_t s) {
 }  // namespace gdx
 
 static int sampler_update_impl(const gdx_update_args_t* a, const int* state, long noise_stride, void* stream);
+
+// internal (api.hip, gdx_sample_loop): one step of the token-major fast path (update_tm_kernel)
+int gdx_sampler_update_tm_(int kind, int B, int J, int T, int ldx, int ldo, const float* coef, int step_index, float* xt,
+                           const float* x0t, const float* scale, int const_noise, uint64_t seed, uint64_t sample_offset,
+                           uint32_t rng_step, int clip, float* out_pose, void* stream) {
+    using namespace gdx;
+    if (!coef || !xt || !x0t || T % 4 || ldx % 4 || ldo % 4 || ldx < (J + 3) / 4 * 4 || ldo < (J + 3) / 4 * 4)
+        return gdx_set_error_("gdx_sampler_update_tm_: bad argument");
+    UpdateTmDev d{kind, B, J, T, ldx, ldo, coef, step_index, xt, x0t, scale, const_noise, seed, sample_offset, rng_step, clip, out_pose};
+    const long total = (long)B * (T / 4) * ((J + 3) / 4);
+    if (total == 0) return 0;
+    hipLaunchKernelGGL(update_tm_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, d);
+    return hipGetLastError() == hipSuccess ? 0 : gdx_set_error_("gdx_sampler_update_tm_: launch failed");
+}
 
 extern "C" int gdx_sampler_update(const gdx_update_args_t* a, void* stream) {
     return sampler_update_impl(a, nullptr, 0, stream);

@@ -298,6 +298,41 @@ def test_inpainting_with_epsilon_raises_like_the_reference():
         df.p_sample_loop(m, tuple(tape[0].shape), noise_tape=tape, model_kwargs={"y": y})
 
 
+# ------------------------------------------------------------------------------------------------ token-major loop state
+@pytest.mark.parametrize("arch,T", [("mdm", 20), ("mdm_old", 20), ("mdm_old", 36), ("mdm", 30), ("mdm_old", 18)])
+@pytest.mark.parametrize("case", ["p", "p_cfg_clip", "ddim_eta05_cfg", "p_const_noise", "p_skip"])
+def test_fused_philox_loop_equals_stepwise_philox_loop(arch, T, case):
+    """gdx_sample_loop with in-kernel Philox noise keeps the state token-major between steps when T % 4 == 0 (update_tm_kernel;
+    T = 20, 36) and takes the general path otherwise (T = 30, 18): both must reproduce, bit for bit, the step-wise protocol
+    (model(x, t, **kw) + one gdx_sampler_update per step) drawing the same Philox stream -- ancestral / DDIM, guidance,
+    clip_denoised, const_noise, skip_timesteps, J = 16 (whole channel quads) and J = 18 (a partial last quad)."""
+    from gesturediffusion_amd.model.cfg_sampler import ClassifierFreeSampleModel
+    from gesturediffusion_amd.utils.init import init_state_dict, synthetic_inputs
+    for J in (16, 18):
+        cfg = dict(TINY, arch=arch, njoints=J)
+        m = build_model(arch, cfg, init_state_dict(cfg, seed=51, perturb=True))
+        B = 3
+        _, seedp, mfcc = synthetic_inputs(cfg, B, T, seed=9)
+        y = {"seed": seedp.to(dev()), "mfcc": mfcc.to(dev())}
+        model = m
+        kw = dict(clip_denoised="clip" in case, model_kwargs={"y": y}, rng="philox", philox_seed=77, sample_offset=5)
+        if "cfg" in case:
+            y["scale"] = torch.tensor([2.5, 1.0, 0.0], device=dev())
+            model = ClassifierFreeSampleModel(m)
+        if case == "p_const_noise":
+            kw["const_noise"] = True
+        if case == "p_skip":
+            kw["skip_timesteps"] = 7
+        if case.startswith("ddim"):
+            df, fn = _diffusion("ddim10"), "ddim_sample_loop"
+            kw["eta"] = 0.5
+        else:
+            df, fn = _diffusion([20]), "p_sample_loop"
+        fused = getattr(df, fn)(model, (B, J, 1, T), **kw)
+        stepwise = getattr(df, fn)(model, (B, J, 1, T), fused=False, **kw)
+        assert torch.isfinite(fused).all() and torch.equal(fused, stepwise), (J, case)
+
+
 # ------------------------------------------------------------------------------------------------ bf16 mode
 BF16_TOL = 2e-2      # SURVEY 8(d): the fp16 / bf16 mode's stated tolerance (measured: forwards 7.6-9.0e-3, loops 5e-3 - 1.2e-2)
 
