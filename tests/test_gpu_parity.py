@@ -391,6 +391,7 @@ def test_error_behaviour_matches_reference(golden_dir):
 
 @pytest.mark.parametrize("extra", [["--arch_version", "mdm_old", "--num_frames", "23", "--guidance_param", "1"],
                                    ["--arch_version", "mdm", "--num_frames", "20", "--compute_dtype", "fp16"],
+                                   ["--arch_version", "mdm_old", "--num_frames", "20", "--compute_dtype", "bf16", "--rng", "philox"],
                                    ["--arch_version", "mdm", "--num_frames", "20", "--synthetic_njoints", "48"],
                                    ["--arch_version", "mdm_old", "--num_frames", "31", "--synthetic_audio"],
                                    ["--arch_version", "mdm", "--num_frames", "20", "--rng", "philox"],
