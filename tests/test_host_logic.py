@@ -315,3 +315,26 @@ def test_packed_image_key_follows_checkpoint_content_arch_and_dtype(tmp_path):
     a.write_bytes(b"weights-2" * 1000)
     assert packed_image_path("cache", str(a), MDM()) != k                                       # same name, other content
 
+
+def test_bench_presets_are_the_baseline_configs():
+    """bench.py --config N must be BASELINE.json's configuration N as SURVEY.md 8(d) spells it out (arch / J / B / T / d / L /
+    respacing / guidance / dtype / how --gpus scales it), and the metric string must name the preset's own loop."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_module", os.path.join(REPO, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    want = {
+        "1": dict(arch="mdm", J=150, d=512, L=8, T=60, batch=4, respacing="ddim10", sampler="ddim", cfg=False, dtype="fp32"),
+        "2": dict(arch="mdm_old", J=263, d=512, L=8, T=196, batch=64, respacing="", sampler="p", cfg=False, dtype="fp32", global_batch=False),
+        "3": dict(arch="mdm_old", J=263, d=512, L=8, T=196, batch=256, respacing="ddim100", sampler="ddim", cfg=True, dtype="fp32"),
+        "4": dict(arch="mdm_old", J=263, d=512, L=8, T=196, batch=2048, sub=256, respacing="", sampler="p", cfg=False, global_batch=True,
+                  scaling="strong"),
+        "5": dict(arch="mdm", J=498, d=1024, L=8, T=520, batch=128, respacing="", sampler="p", cfg=False, dtype="fp16", global_batch=True,
+                  scaling="strong"),
+    }
+    for name, fields in want.items():
+        for k, v in fields.items():
+            assert bench.PRESETS[name][k] == v, (name, k)
+    assert bench.PRESETS["2"]["scaling"] == "weak"          # the headline: 64 samples per GPU
+    assert bench.SCHEDULE_STEPS == 1000 and bench.F32_MFMA_PEAK_TFLOPS == 157.3 and bench.F16_MFMA_PEAK_TFLOPS == 2500.0
+
