@@ -333,6 +333,34 @@ def test_fused_philox_loop_equals_stepwise_philox_loop(arch, T, case):
         assert torch.isfinite(fused).all() and torch.equal(fused, stepwise), (J, case)
 
 
+@pytest.mark.parametrize("arch,T", [("mdm_old", 196), ("mdm", 200)])
+def test_whole_loop_at_config2_shapes_vs_oracle(arch, T):
+    """A whole respaced ancestral loop (250 steps of the 1000-step schedule) at BASELINE config 2's model shapes (J = 263,
+    d = 512, L = 8; V1 at T = 196, V2 at T = 200), fused with in-kernel Philox noise (token-major loop state), against the CPU
+    oracle fed the same Philox stream.  (tools/full_loop_parity.py runs the full 1000 steps: 1.2e-6 / 1.4e-6,
+    profiles/r02j_full_loop_parity.txt; the contract is 1e-3.)"""
+    from gesturediffusion_amd.utils.init import init_state_dict, synthetic_inputs
+    from oracle import mdm_forward as omf
+    from oracle import philox
+    from oracle import sampler as osamp
+    from oracle import schedule as osch
+    cfg = _real_cfg(arch, 263, 512)
+    sd = init_state_dict(cfg, seed=0)
+    m = build_model(arch, cfg, sd)
+    B, J, steps = 2, 263, 250
+    _, seedp, mfcc = synthetic_inputs(cfg, B, T, seed=10)
+    y = {"seed": seedp.to(dev()), "mfcc": mfcc.to(dev())}
+    out = _diffusion([steps]).p_sample_loop(m, (B, J, 1, T), clip_denoised=False, model_kwargs={"y": y}, rng="philox",
+                                            philox_seed=10).cpu()
+    tab, tmap = osch.make_tables("cosine", 1000, [steps])
+    tape = torch.stack([torch.from_numpy(philox.normal(B, J * T, 10, 0, k)).view(B, J, 1, T) for k in range(steps + 1)])
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    with torch.no_grad():
+        want = osamp.sample_loop(lambda x, t, yy: omf.forward(sd, cfg, x, t, yy), tab, tmap, (B, J, 1, T), tape,
+                                 {"seed": seedp, "mfcc": mfcc}, kind="p")
+    assert rel_err(out, want) < 2e-5
+
+
 # ------------------------------------------------------------------------------------------------ bf16 mode
 BF16_TOL = 2e-2      # SURVEY 8(d): the fp16 / bf16 mode's stated tolerance (measured: forwards 7.6-9.0e-3, loops 5e-3 - 1.2e-2)
 
