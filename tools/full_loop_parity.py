@@ -39,3 +39,21 @@ for arch, J, T, steps in (("mdm_old", 263, 196, int(sys.argv[1])), ("mdm", 263, 
     tc = time.time() - t0
     err = float((out - want).abs().max() / want.abs().max())
     print(f"{arch} T={T} {n}-step ancestral loop, B={B}: GPU {tg:.1f} s, oracle {tc:.1f} s, rel err {err:.2e}, max|ref| {float(want.abs().max()):.3f}", flush=True)
+
+# BASELINE config 3's loop: 100-step DDIM (eta 0) under classifier-free guidance 2.5, V1 topology, T = 196
+from gesturediffusion_amd.model.cfg_sampler import ClassifierFreeSampleModel
+arch, J, T, B = "mdm_old", 263, 196, 2
+cfg = _real_cfg(arch, J, 512)
+sd = init_state_dict(cfg, seed=0)
+m = ClassifierFreeSampleModel(build_model(arch, cfg, sd))
+_, seedp, mfcc = synthetic_inputs(cfg, B, T, seed=10)
+scale = torch.full((B,), 2.5)
+y = {"seed": seedp.to(dev()), "mfcc": mfcc.to(dev()), "scale": scale.to(dev())}
+out = _diffusion("ddim100").ddim_sample_loop(m, (B, J, 1, T), clip_denoised=False, model_kwargs={"y": y}, rng="philox", philox_seed=10).cpu()
+tab, tmap = osch.make_tables("cosine", 1000, "ddim100")
+tape = torch.stack([torch.from_numpy(philox.normal(B, J * T, 10, 0, k)).view(B, J, 1, T) for k in range(101)])
+with torch.no_grad():
+    want = osamp.sample_loop(lambda x, t, yy: omf.cfg_forward(sd, cfg, x, t, yy), tab, tmap, (B, J, 1, T), tape,
+                             {"seed": seedp, "mfcc": mfcc, "scale": scale}, kind="ddim")
+print(f"config-3 loop (100-step DDIM + CFG 2.5, {arch} T={T}, B={B}): rel err {float((out - want).abs().max() / want.abs().max()):.2e}", flush=True)
+
