@@ -80,7 +80,7 @@ namespace gdx { extern unsigned long long* g2_dbg_buf; }
 int gdx_sampler_update_state_(const gdx_update_args_t* a, const int* state, long noise_stride, void* stream);   // sampler.hip
 int gdx_sampler_update_tm_(int kind, int B, int J, int T, int ldx, int ldo, const float* coef, int step_index, float* xt,
                            const float* x0t, const float* scale, int const_noise, uint64_t seed, uint64_t sample_offset,
-                           uint32_t rng_step, int clip, float* out_pose, void* stream);                                  // sampler.hip
+                           uint32_t rng_step, int clip, float* out_pose, void* xt16, int half_dtype, void* stream);      // sampler.hip
 
 struct gdx_model {
     gdx_config_t cfg;
@@ -586,6 +586,7 @@ extern "C" int gdx_prepare(gdx_handle_t h, int32_t batch, int32_t frames) {
     const size_t NT = B2 * frames + GDX_ROW_PAD;
     if (A(&h->x0t, NT * h->ldo)) return -1;
     if (!h->f16 && (A(&h->xt, NT * round_up(h->J, 32)) || A(&h->xc, NT * d))) return -1;
+    if (h->f16 && A(&h->xt, NT * round_up(h->J, 64))) return -1;      // fp32 loop state of the token-major fast path (gdx_sample_loop)
     if (h->cfg.arch == GDX_ARCH_MDM && A(&h->xseq, NT * d)) return -1;
     if (h->cfg.arch == GDX_ARCH_MDM && !h->f16 && A(&h->emb_pose, NT * d)) return -1;
     if (h->f16) {
@@ -707,7 +708,7 @@ static int gemm(int am, int bm, int om, int ep, const GemmParams& p, hipStream_t
 // The per-step kernel sequence.  temb: [*, d] rows (row stride tstride, 0 = shared by the batch).
 // Writes x0 for Beff samples into x0_out ([Beff, J, T]).
 static int forward_core_f16(gdx_model* h, const float* x, const float* temb, int tstride, const float* c2t, int mode,
-                            float* x0_out, hipStream_t s, const int* state);
+                            float* x0_out, hipStream_t s, const int* state, bool tm = false);
 
 // c2t (V2 only): W_coa * temb rows with the same row stride as temb -- the timestep half of the coarse slice of
 // project_to_lat (model/mdm.py:154-169), computed by the caller with the row-independent small_linear kernel: per
@@ -718,7 +719,7 @@ static int forward_core_f16(gdx_model* h, const float* x, const float* temb, int
 // both token-major -- neither transpose runs (x / x0_out unused).
 static int forward_core(gdx_model* h, const float* x, const float* temb, int tstride, const float* c2t, int mode,
                         float* x0_out, hipStream_t s, const int* state = nullptr, bool tm = false) {
-    if (h->f16) return forward_core_f16(h, x, temb, tstride, c2t, mode, x0_out, s, state);
+    if (h->f16) return forward_core_f16(h, x, temb, tstride, c2t, mode, x0_out, s, state, tm);
     const int B = h->B, T = h->T, S = h->S, d = h->d, J = h->J;
     const int Beff = mode == GDX_CFG ? 2 * B : B;
     const float* seed_emb = mode == GDX_UNCOND ? h->seed_cat + (size_t)B * d : h->seed_cat;
@@ -807,14 +808,14 @@ static int gemm_f16(bool bf, const _Float16* A, int lda, const Packed& P, const 
 // accumulation (MFMA, bias / residual terms in the GEMM epilogues, LayerNorm statistics, softmax) is fp32.  The two
 // boundary tensors stay fp32: the pose tensor read by the input transpose and the x0 prediction (fp32 output GEMM).
 static int forward_core_f16(gdx_model* h, const float* x, const float* temb, int tstride, const float* c2t, int mode,
-                            float* x0_out, hipStream_t s, const int* state) {
+                            float* x0_out, hipStream_t s, const int* state, bool tm) {
     const int B = h->B, T = h->T, S = h->S, d = h->d, J = h->J;
     const int Beff = mode == GDX_CFG ? 2 * B : B;
     const float* seed_emb = mode == GDX_UNCOND ? h->seed_cat + (size_t)B * d : h->seed_cat;
     const int N = Beff * S;
     const int Jp = h->in_x.kpad16;
     float* const tap32 = h->keep_taps ? h->xa : nullptr;              // fp32 copies only for the parity taps
-    HIPCHK(HFN(h->bf16, launch_transpose_in_f16, x, h->xt16, Beff, B, J, T, Jp, s));
+    if (!tm) HIPCHK(HFN(h->bf16, launch_transpose_in_f16, x, h->xt16, Beff, B, J, T, Jp, s));   // tm: the update kernel wrote xt16
     if (h->cfg.arch == GDX_ARCH_MDM_OLD) {
         HIPCHK(HFN(h->bf16, launch_token0, temb, tstride, seed_emb, h->pe, h->xa, h->xa16, nullptr, nullptr, nullptr, state, Beff, B, S, d, s));
         if (gemm_f16(h->bf16, h->xt16, Jp, h->in_x, nullptr, h->addend, d, nullptr, 0, tap32, d, h->xa16, d, Beff * T, d, T, 1, 0, s))
@@ -864,7 +865,7 @@ static int forward_core_f16(gdx_model* h, const float* x, const float* temb, int
     }
     if (gemm_f16(h->bf16, h->xc16, d, h->outp, h->outp.bias, nullptr, 0, nullptr, 0, h->x0t, h->ldo, nullptr, 0, Beff * T, h->ldo, T, 0, 0, s))
         return -1;
-    HIPCHK(launch_transpose_out(h->x0t, x0_out, Beff, J, T, h->ldo, s));
+    if (!tm) HIPCHK(launch_transpose_out(h->x0t, x0_out, Beff, J, T, h->ldo, s));
     return 0;
 }
 
@@ -996,17 +997,21 @@ extern "C" int gdx_sample_loop(gdx_handle_t h, const gdx_loop_args_t* a, void* s
     // call -- one transpose in front, none per step (2 launches and ~40 MB per step less), the last update also writes the
     // sample in the reference layout.  Bit-identical to the general path (tests: fused Philox loop == step-wise Philox loop).
     static const bool no_tm = getenv("GDX_LOOP_NO_TM") != nullptr;           // A/B switch
-    if (!no_tm && !h->f16 && !a->noise_tape && !a->inpaint_mask && !a->n_dump && !h->graph_replay && !h->keep_taps && h->T % 4 == 0) {
+    if (!no_tm && !a->noise_tape && !a->inpaint_mask && !a->n_dump && !h->graph_replay && !h->keep_taps && h->T % 4 == 0) {
         const int Beff = a->mode == GDX_CFG ? 2 * B : B;
-        HIPCHK(launch_transpose_in(a->x, h->xt, Beff, B, h->J, h->T, h->in_x.kpad, s));
+        // half modes: the fp32 state keeps the half operand's row stride, and the update kernel also writes that operand
+        const int ldx = h->f16 ? h->in_x.kpad16 : h->in_x.kpad;
+        HIPCHK(launch_transpose_in(a->x, h->xt, Beff, B, h->J, h->T, ldx, s));
+        if (h->f16) HIPCHK(HFN(h->bf16, launch_transpose_in_f16, a->x, h->xt16, Beff, B, h->J, h->T, ldx, s));
         int k = a->k_base;
         for (int idx = a->first_index; idx >= last_idx; --idx, ++k) {
             if (forward_core(h, nullptr, table + (size_t)idx * d, 0, h->c2t_table ? h->c2t_table + (size_t)idx * d : nullptr, a->mode,
                              nullptr, s, nullptr, true))
                 return -1;
-            if (gdx_sampler_update_tm_(a->kind, B, h->J, h->T, h->in_x.kpad, h->ldo, a->coef, idx, h->xt, h->x0t,
+            if (gdx_sampler_update_tm_(a->kind, B, h->J, h->T, ldx, h->ldo, a->coef, idx, h->xt, h->x0t,
                                        a->mode == GDX_CFG ? a->scale : nullptr, a->const_noise, a->philox_seed, a->sample_offset,
-                                       (uint32_t)(k + 1), a->clip_denoised, idx == last_idx ? a->x : nullptr, stream))
+                                       (uint32_t)(k + 1), a->clip_denoised, idx == last_idx ? a->x : nullptr,
+                                       h->f16 ? (void*)h->xt16 : nullptr, h->cfg.compute_dtype, stream))
                 return -1;
         }
         return 0;

@@ -172,6 +172,8 @@ struct UpdateTmDev {
     uint32_t rng_step;
     int clip;
     float* out_pose;        // [B][J][T] or nullptr (last step)
+    void* xt16;             // half modes: the input GEMM's 16-bit operand [Beff*T][ldx], written beside the fp32 state
+    int half_dtype;         // GDX_DTYPE_F16 or GDX_DTYPE_BF16 (the element type of xt16)
 };
 
 __device__ __forceinline__ float update_value(int kind, const float* c, float x, float x0, float z) {
@@ -234,6 +236,23 @@ __global__ __launch_bounds__(256) void update_tm_kernel(const UpdateTmDev a) {
     for (int tt = 0; tt < 4; ++tt) {
         *reinterpret_cast<f32x4*>(a.xt + (row0 + tt) * a.ldx + j0) = r[tt];
         if (a.scale) *reinterpret_cast<f32x4*>(a.xt + (urow + row0 + tt) * a.ldx + j0) = r[tt];
+    }
+    if (a.xt16) {                                                  // the same values rounded once, as transpose_in_f16 would
+        typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+        typedef __bf16 b4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt) {
+            const long o0 = (row0 + tt) * a.ldx + j0, o1 = o0 + urow * a.ldx;
+            if (a.half_dtype == GDX_DTYPE_BF16) {
+                const b4 v = b4{(__bf16)r[tt][0], (__bf16)r[tt][1], (__bf16)r[tt][2], (__bf16)r[tt][3]};
+                *reinterpret_cast<b4*>((__bf16*)a.xt16 + o0) = v;
+                if (a.scale) *reinterpret_cast<b4*>((__bf16*)a.xt16 + o1) = v;
+            } else {
+                const h4 v = h4{(_Float16)r[tt][0], (_Float16)r[tt][1], (_Float16)r[tt][2], (_Float16)r[tt][3]};
+                *reinterpret_cast<h4*>((_Float16*)a.xt16 + o0) = v;
+                if (a.scale) *reinterpret_cast<h4*>((_Float16*)a.xt16 + o1) = v;
+            }
+        }
     }
     if (a.out_pose) {
 #pragma unroll
@@ -403,11 +422,12 @@ static int sampler_update_impl(const gdx_update_args_t* a, const int* state, lon
 // internal (api.hip, gdx_sample_loop): one step of the token-major fast path (update_tm_kernel)
 int gdx_sampler_update_tm_(int kind, int B, int J, int T, int ldx, int ldo, const float* coef, int step_index, float* xt,
                            const float* x0t, const float* scale, int const_noise, uint64_t seed, uint64_t sample_offset,
-                           uint32_t rng_step, int clip, float* out_pose, void* stream) {
+                           uint32_t rng_step, int clip, float* out_pose, void* xt16, int half_dtype, void* stream) {
     using namespace gdx;
     if (!coef || !xt || !x0t || T % 4 || ldx % 4 || ldo % 4 || ldx < (J + 3) / 4 * 4 || ldo < (J + 3) / 4 * 4)
         return gdx_set_error_("gdx_sampler_update_tm_: bad argument");
-    UpdateTmDev d{kind, B, J, T, ldx, ldo, coef, step_index, xt, x0t, scale, const_noise, seed, sample_offset, rng_step, clip, out_pose};
+    UpdateTmDev d{kind, B, J, T, ldx, ldo, coef, step_index, xt, x0t, scale, const_noise, seed, sample_offset, rng_step, clip, out_pose,
+                  xt16, half_dtype};
     const long total = (long)B * (T / 4) * ((J + 3) / 4);
     if (total == 0) return 0;
     hipLaunchKernelGGL(update_tm_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, d);

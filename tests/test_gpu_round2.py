@@ -299,18 +299,13 @@ def test_inpainting_with_epsilon_raises_like_the_reference():
 
 
 # ------------------------------------------------------------------------------------------------ token-major loop state
-@pytest.mark.parametrize("arch,T", [("mdm", 20), ("mdm_old", 20), ("mdm_old", 36), ("mdm", 30), ("mdm_old", 18)])
-@pytest.mark.parametrize("case", ["p", "p_cfg_clip", "ddim_eta05_cfg", "p_const_noise", "p_skip"])
-def test_fused_philox_loop_equals_stepwise_philox_loop(arch, T, case):
-    """gdx_sample_loop with in-kernel Philox noise keeps the state token-major between steps when T % 4 == 0 (update_tm_kernel;
-    T = 20, 36) and takes the general path otherwise (T = 30, 18): both must reproduce, bit for bit, the step-wise protocol
-    (model(x, t, **kw) + one gdx_sampler_update per step) drawing the same Philox stream -- ancestral / DDIM, guidance,
-    clip_denoised, const_noise, skip_timesteps, J = 16 (whole channel quads) and J = 18 (a partial last quad)."""
+def _fused_vs_stepwise_philox(arch, T, case, compute_dtype):
     from gesturediffusion_amd.model.cfg_sampler import ClassifierFreeSampleModel
     from gesturediffusion_amd.utils.init import init_state_dict, synthetic_inputs
     for J in (16, 18):
         cfg = dict(TINY, arch=arch, njoints=J)
         m = build_model(arch, cfg, init_state_dict(cfg, seed=51, perturb=True))
+        m.compute_dtype = compute_dtype
         B = 3
         _, seedp, mfcc = synthetic_inputs(cfg, B, T, seed=9)
         y = {"seed": seedp.to(dev()), "mfcc": mfcc.to(dev())}
@@ -331,6 +326,25 @@ def test_fused_philox_loop_equals_stepwise_philox_loop(arch, T, case):
         fused = getattr(df, fn)(model, (B, J, 1, T), **kw)
         stepwise = getattr(df, fn)(model, (B, J, 1, T), fused=False, **kw)
         assert torch.isfinite(fused).all() and torch.equal(fused, stepwise), (J, case)
+
+
+@pytest.mark.parametrize("arch,T", [("mdm", 20), ("mdm_old", 20), ("mdm_old", 36), ("mdm", 30), ("mdm_old", 18)])
+@pytest.mark.parametrize("case", ["p", "p_cfg_clip", "ddim_eta05_cfg", "p_const_noise", "p_skip"])
+def test_fused_philox_loop_equals_stepwise_philox_loop(arch, T, case):
+    """gdx_sample_loop with in-kernel Philox noise keeps the state token-major between steps when T % 4 == 0 (update_tm_kernel;
+    T = 20, 36) and takes the general path otherwise (T = 30, 18): both must reproduce, bit for bit, the step-wise protocol
+    (model(x, t, **kw) + one gdx_sampler_update per step) drawing the same Philox stream -- ancestral / DDIM, guidance,
+    clip_denoised, const_noise, skip_timesteps, J = 16 (whole channel quads) and J = 18 (a partial last quad)."""
+    _fused_vs_stepwise_philox(arch, T, case, "fp32")
+
+
+@pytest.mark.parametrize("arch,T", [("mdm", 20), ("mdm_old", 36), ("mdm_old", 18)])
+@pytest.mark.parametrize("case", ["p_cfg_clip", "ddim_eta05_cfg"])
+@pytest.mark.parametrize("dtype", ["fp16", "bf16"])
+def test_fused_philox_loop_equals_stepwise_in_the_half_modes(arch, T, case, dtype):
+    """The same in the fp16 / bf16 modes: there the token-major update also writes the input GEMM's 16-bit operand (rounded
+    once from the fp32 state, like the transpose it replaces)."""
+    _fused_vs_stepwise_philox(arch, T, case, dtype)
 
 
 @pytest.mark.parametrize("arch,T", [("mdm_old", 196), ("mdm", 200)])
