@@ -1308,7 +1308,7 @@ extern "C" int gdx_attention_f32(const float* qkv, float* ctx, int32_t B, int32_
     if (!qkv || !ctx || B <= 0 || S <= 0 || H <= 0 || d <= 0 || d % H) return fail("gdx_attention_f32: bad argument");
     const int hd = d / H;
     if (hd != 32 && hd != 64 && hd != 128 && hd != 256) return fail("gdx_attention_f32: head_dim must be 32, 64, 128 or 256");
-    if ((version == 2 && !attention2_supported(S, H, d)) || (version == 3 && !attention3_supported(S, H, d)))
+    if ((version == 2 && !attention2_supported(S, H, d)) || ((version == 3 || version == 5) && !attention3_supported(S, H, d)))
         return fail("gdx_attention_f32: shape not supported by the requested kernel");
     hipStream_t s = (hipStream_t)stream;
     const size_t rows = (size_t)B * S, prow = rows + GDX_ROW_PAD;
@@ -1321,7 +1321,8 @@ extern "C" int gdx_attention_f32(const float* qkv, float* ctx, int32_t B, int32_
         rc = fail("gdx_attention_f32: staging failed");
     if (!rc) {
         hipError_t e;
-        if (version == 3 || (version == 0 && attention3_supported(S, H, d))) e = launch_attention3(q, c, B, S, H, d, s);
+        if (version == 5) e = launch_attention3(q, c, B, S, H, d, s, (B * H + 2) / 3);   // persistent, ~3 items per workgroup
+        else if (version == 3 || (version == 0 && attention3_supported(S, H, d))) e = launch_attention3(q, c, B, S, H, d, s);
         else if (version == 2 || (version == 0 && attention2_supported(S, H, d))) e = launch_attention2(q, c, B, S, H, d, s);
         else e = launch_attention(q, c, B, S, H, d, s);
         if (e != hipSuccess) rc = fail(std::string("gdx_attention_f32: ") + hipGetErrorString(e));
@@ -1355,6 +1356,7 @@ extern "C" int gdx_bench_gemm_f16(int32_t M, int32_t N, int32_t K, int32_t gelu,
         rc = fail("gdx_bench_gemm_f16: operand fill failed");
     GemmHParams p{a16, K, w16, K, (int)((size_t)M * K * 2), (int)((size_t)npad * K * 2), bias, nullptr, 0, nullptr, 0,
                   nullptr, 0, c16, N, M, N, K, 1, 0, gelu};
+    if (getenv("GDX_BENCH_GEMM_R") && N <= K) { p.R = Af; p.ldr = N; }   // diagnostic: an fp32 per-row term streamed by the epilogue
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (!rc && (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess)) rc = fail("hipEventCreate failed");
     for (int i = 0; !rc && i < 3; ++i)

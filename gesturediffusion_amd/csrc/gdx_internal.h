@@ -89,7 +89,8 @@ hipError_t launch_attention2(const float* qkv, float* ctx, int B, int S, int H, 
 // eight-wave single-pass variant with the last query block shared out over four waves (attention3.hip); needs 64
 // readable rows past the last sample
 bool attention3_supported(int S, int H, int d);
-hipError_t launch_attention3(const float* qkv, float* ctx, int B, int S, int H, int d, hipStream_t s);
+// grid > 0: the persistent variant on that many workgroups (default: chosen from the item count)
+hipError_t launch_attention3(const float* qkv, float* ctx, int B, int S, int H, int d, hipStream_t s, int grid = 0);
 
 // ---- misc (misc.hip) ---------------------------------------------------------------------
 // ---- everything below exists once per half type (see the top of this file): gdx::X is the fp16 / fp32 build, gdx::b16::X

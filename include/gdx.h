@@ -312,7 +312,8 @@ int gdx_set_test_half_dtype(int32_t dtype);
 /* ctx = softmax(Q K^T / sqrt(hd)) V per (sample, head) through the fp32 attention kernels: the SDPA inside
  * nn.MultiheadAttention of the encoder layers (model/mdm.py:90-96).  qkv [B*S][3d], ctx [B*S][d] fp32 device arrays.
  * version 0 = the choice gdx_forward makes, 1 = 32x32-block kernel (attention.hip), 2 = attention2.hip,
- * 3 = attention3.hip.  Test entry point: works on a padded scratch copy and synchronises the stream. */
+ * 3 = attention3.hip, 5 = attention3.hip's persistent variant on ceil(B*H / 3) workgroups.  Test entry point: works on
+ * a padded scratch copy and synchronises the stream. */
 int gdx_attention_f32(const float* qkv, float* ctx, int32_t B, int32_t S, int32_t H, int32_t d, int32_t version,
                       void* stream);
 /* Time `iters` launches of the fp16 GEMM on scratch operands filled with N(0,1). */

@@ -474,20 +474,21 @@ def test_fp16_attention_vs_torch(B, S, H, dm):
     assert rel_err(ctx.cpu().double(), ref.cpu()) < 2e-3
 
 
-@pytest.mark.parametrize("version", [1, 2, 3])
+@pytest.mark.parametrize("version", [1, 2, 3, 5])
 @pytest.mark.parametrize("B,S,H,dm", [(3, 197, 4, 512), (2, 201, 4, 512), (2, 61, 4, 512), (2, 65, 4, 512), (2, 129, 4, 512),
                                       (1, 256, 4, 512), (2, 241, 4, 512), (3, 1, 4, 512), (2, 16, 4, 512), (2, 197, 8, 512),
                                       (2, 81, 2, 128), (66, 197, 4, 512)])
 def test_fp32_attention_vs_torch(B, S, H, dm, version):
-    """The three fp32 SDPA kernels (csrc/attention.hip, attention2.hip, attention3.hip) against fp64 softmax attention:
-    the BASELINE sequence lengths (197, 201, 61), every 4k + 1 block count that makes attention3 share the last query
-    block out over four waves (65, 129, 197), full 16 blocks, one token, head_dim 64 and 128, more workgroups than CUs."""
+    """The three fp32 SDPA kernels (csrc/attention.hip, attention2.hip, attention3.hip; version 5 = attention3's persistent
+    variant, every workgroup walking ~3 (sample, head) items) against fp64 softmax attention: the BASELINE sequence
+    lengths (197, 201, 61), every 4k + 1 block count that makes attention3 share the last query block out over four
+    waves (65, 129, 197), full 16 blocks, one token, head_dim 64 and 128, more workgroups than CUs."""
     import ctypes as C
     from gesturediffusion_amd import _lib
     lib = _lib.load()
     d = dev()
     hd = dm // H
-    g = torch.Generator(device=d).manual_seed(S + version)
+    g = torch.Generator(device=d).manual_seed(S + min(version, 3))   # version 5 sees version 3's data
     qkv = torch.randn(B * S, 3 * dm, device=d, generator=g)
     qkv[:, :dm] *= 3.0                                   # peaked rows: exercises the deferred-max rescale
     ctx = torch.full((B * S, dm), float("nan"), device=d)
@@ -517,13 +518,17 @@ def test_fp32_attention3_every_block_count(hd):
             g = torch.Generator(device=d).manual_seed(1000 * hd + S)
             qkv = torch.randn(B * S, 3 * dm, device=d, generator=g)
             qkv[:, :dm] *= 2.0
-            ctx = torch.full((B * S, dm), float("nan"), device=d)
-            _lib.check(lib.gdx_attention_f32(C.c_void_p(qkv.data_ptr()), C.c_void_p(ctx.data_ptr()), B, S, H, dm, 3, s), lib)
             r = qkv.double().view(B, S, 3, H, hd)
             q, kk, v = (r[:, :, i].permute(0, 2, 1, 3) for i in range(3))
             p = torch.softmax(q @ kk.transpose(-1, -2) / hd ** 0.5, dim=-1)
             ref = (p @ v).permute(0, 2, 1, 3).reshape(B * S, dm)
-            assert rel_err(ctx.cpu().double(), ref.cpu()) < 2e-6, (hd, S)
+            outs = []
+            for version in (3, 5):                        # item-resident / persistent (2 workgroups x 3 items)
+                ctx = torch.full((B * S, dm), float("nan"), device=d)
+                _lib.check(lib.gdx_attention_f32(C.c_void_p(qkv.data_ptr()), C.c_void_p(ctx.data_ptr()), B, S, H, dm, version, s), lib)
+                assert rel_err(ctx.cpu().double(), ref.cpu()) < 2e-6, (hd, S, version)
+                outs.append(ctx)
+            assert torch.equal(outs[0], outs[1]), (hd, S)   # same arithmetic per item
 
 
 @pytest.mark.parametrize("name,arch,J,dm", [("c1_v2", "mdm", 150, 512), ("c2_v1", "mdm_old", 263, 512),
