@@ -80,7 +80,7 @@ namespace gdx { extern unsigned long long* g2_dbg_buf; }
 int gdx_sampler_update_state_(const gdx_update_args_t* a, const int* state, long noise_stride, void* stream);   // sampler.hip
 int gdx_sampler_update_tm_(int kind, int B, int J, int T, int ldx, int ldo, const float* coef, int step_index, float* xt,
                            const float* x0t, const float* scale, int const_noise, uint64_t seed, uint64_t sample_offset,
-                           uint32_t rng_step, int clip, float* out_pose, void* xt16, int half_dtype, void* stream);      // sampler.hip
+                           uint32_t rng_step, int clip, float* out_pose, void* xt16, int half_dtype, void* stream, const float* noise);      // sampler.hip
 
 struct gdx_model {
     gdx_config_t cfg;
@@ -992,12 +992,12 @@ extern "C" int gdx_sample_loop(gdx_handle_t h, const gdx_loop_args_t* a, void* s
     // ~65 small kernels of a step are bound by their GPU-side dispatch + ramp, not by host launch time, and a graph
     // node costs slightly more than a stream launch; so it is OFF by default and kept as a switch.
     const int last_idx = a->run_steps > 0 && a->run_steps <= a->first_index ? a->first_index - a->run_steps + 1 : 0;
-    // Token-major fast path (sampler.hip, update_tm_kernel): with in-kernel Philox noise and nothing else that lives in the
-    // reference layout (no noise tape, inpainting, dumps), the state stays in the input GEMM's operand layout for the whole
+    // Token-major fast path (sampler.hip, update_tm_kernel): with nothing but the noise tape living in the reference layout
+    // (no inpainting, no dumps; the tape is read in place), the state stays in the input GEMM's operand layout for the whole
     // call -- one transpose in front, none per step (2 launches and ~40 MB per step less), the last update also writes the
     // sample in the reference layout.  Bit-identical to the general path (tests: fused Philox loop == step-wise Philox loop).
     static const bool no_tm = getenv("GDX_LOOP_NO_TM") != nullptr;           // A/B switch
-    if (!no_tm && !a->noise_tape && !a->inpaint_mask && !a->n_dump && !h->graph_replay && !h->keep_taps && h->T % 4 == 0) {
+    if (!no_tm && !((uintptr_t)a->noise_tape & 15) && !a->inpaint_mask && !a->n_dump && !h->graph_replay && !h->keep_taps && h->T % 4 == 0) {
         const int Beff = a->mode == GDX_CFG ? 2 * B : B;
         // half modes: the fp32 state keeps the half operand's row stride, and the update kernel also writes that operand
         const int ldx = h->f16 ? h->in_x.kpad16 : h->in_x.kpad;
@@ -1011,7 +1011,8 @@ extern "C" int gdx_sample_loop(gdx_handle_t h, const gdx_loop_args_t* a, void* s
             if (gdx_sampler_update_tm_(a->kind, B, h->J, h->T, ldx, h->ldo, a->coef, idx, h->xt, h->x0t,
                                        a->mode == GDX_CFG ? a->scale : nullptr, a->const_noise, a->philox_seed, a->sample_offset,
                                        (uint32_t)(k + 1), a->clip_denoised, idx == last_idx ? a->x : nullptr,
-                                       h->f16 ? (void*)h->xt16 : nullptr, h->cfg.compute_dtype, stream))
+                                       h->f16 ? (void*)h->xt16 : nullptr, h->cfg.compute_dtype, stream,
+                                       a->noise_tape ? a->noise_tape + (size_t)(k - a->k_base) * (a->const_noise ? 1 : B) * per : nullptr))
                 return -1;
         }
         return 0;

@@ -174,6 +174,7 @@ struct UpdateTmDev {
     float* out_pose;        // [B][J][T] or nullptr (last step)
     void* xt16;             // half modes: the input GEMM's 16-bit operand [Beff*T][ldx], written beside the fp32 state
     int half_dtype;         // GDX_DTYPE_F16 or GDX_DTYPE_BF16 (the element type of xt16)
+    const float* noise;     // this step's slice of a noise tape, reference layout [B or 1][J][T], or nullptr (Philox)
 };
 
 __device__ __forceinline__ float update_value(int kind, const float* c, float x, float x0, float z) {
@@ -224,7 +225,8 @@ __global__ __launch_bounds__(256) void update_tm_kernel(const UpdateTmDev a) {
     for (int jj = 0; jj < 4; ++jj) {
         const int j = j0 + jj;
         if (j < a.J) {
-            const f32x4 z = philox_normal4(a.seed, sample, a.rng_step, (uint32_t)(j * tq_n + tq));   // frames t0 .. t0+3 of channel j
+            const f32x4 z = a.noise ? *reinterpret_cast<const f32x4*>(a.noise + ((long)(a.const_noise ? 0 : b) * a.J + j) * a.T + t0)
+                                    : philox_normal4(a.seed, sample, a.rng_step, (uint32_t)(j * tq_n + tq));   // frames t0 .. t0+3 of channel j
 #pragma unroll
             for (int tt = 0; tt < 4; ++tt) r[tt][jj] = update_value(a.kind, c, x[tt][jj], x0[tt][jj], z[tt]);
         } else {
@@ -422,12 +424,13 @@ static int sampler_update_impl(const gdx_update_args_t* a, const int* state, lon
 // internal (api.hip, gdx_sample_loop): one step of the token-major fast path (update_tm_kernel)
 int gdx_sampler_update_tm_(int kind, int B, int J, int T, int ldx, int ldo, const float* coef, int step_index, float* xt,
                            const float* x0t, const float* scale, int const_noise, uint64_t seed, uint64_t sample_offset,
-                           uint32_t rng_step, int clip, float* out_pose, void* xt16, int half_dtype, void* stream) {
+                           uint32_t rng_step, int clip, float* out_pose, void* xt16, int half_dtype, void* stream, const float* noise) {
     using namespace gdx;
     if (!coef || !xt || !x0t || T % 4 || ldx % 4 || ldo % 4 || ldx < (J + 3) / 4 * 4 || ldo < (J + 3) / 4 * 4)
         return gdx_set_error_("gdx_sampler_update_tm_: bad argument");
+    if (noise && ((uintptr_t)noise & 15)) return gdx_set_error_("gdx_sampler_update_tm_: noise tape not 16-byte aligned");
     UpdateTmDev d{kind, B, J, T, ldx, ldo, coef, step_index, xt, x0t, scale, const_noise, seed, sample_offset, rng_step, clip, out_pose,
-                  xt16, half_dtype};
+                  xt16, half_dtype, noise};
     const long total = (long)B * (T / 4) * ((J + 3) / 4);
     if (total == 0) return 0;
     hipLaunchKernelGGL(update_tm_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, d);

@@ -111,6 +111,30 @@ def test_reference_callers_kwargs_take_the_fused_loop_and_match_stepwise(arch, c
     assert torch.isfinite(fused).all() and torch.equal(fused, stepwise)
 
 
+@pytest.mark.parametrize("dtype", ["fp32", "fp16", "bf16"])
+def test_torch_generator_loop_token_major_partial_quad_and_half_modes(dtype):
+    """The fused loop keeps its state token-major also when the noise comes from a pre-drawn tape (torch's generator,
+    the reference caller's default): J = 18 (the last channel quad is partial, the tape rows are read in place), fp32 and
+    the two 16-bit modes, guidance on; bit-identical to the step-wise seam under the same fixseed."""
+    from gesturediffusion_amd.model.cfg_sampler import ClassifierFreeSampleModel
+    from gesturediffusion_amd.utils.fixseed import fixseed
+    from gesturediffusion_amd.utils.init import init_state_dict, synthetic_inputs
+    cfg = dict(TINY, arch="mdm", njoints=18)
+    m = build_model("mdm", cfg, init_state_dict(cfg, seed=4, perturb=True))
+    m.compute_dtype = dtype
+    d = dev()
+    B, T = 3, 40                                      # V2: T % 10 == 0 (local-attention windows); token-major: T % 4 == 0
+    _, seedp, mfcc = synthetic_inputs(cfg, B, T, seed=6)
+    y = {"seed": seedp.to(d), "mfcc": mfcc.to(d), "scale": torch.tensor([2.5, 1.0, 0.0], device=d)}
+    model = ClassifierFreeSampleModel(m)
+    df = _diffusion([60])
+    outs = []
+    for fused in (True, False):
+        fixseed(12)
+        outs.append(df.p_sample_loop(model, (B, 18, 1, T), clip_denoised=True, model_kwargs={"y": y}, progress=fused, fused=fused))
+    assert torch.isfinite(outs[0]).all() and torch.equal(outs[0], outs[1])
+
+
 def test_condition_cache_does_not_alias_freed_views():
     """The reference hands chunk c+1 the seed poses as a non-contiguous VIEW of chunk c's output
     (`sample/generate.py:104-107`).  Two requests whose views have the same address, version counter, shape and strides
