@@ -582,7 +582,14 @@ __global__ __launch_bounds__(256) void local_attention_h_kernel(const half_t* __
     la_f16x8 kf[2][NKS], qf[NKS];
     load_rot(k0 + l15, kf[0]);
     load_rot(k0 + 16 + l15, kf[1]);
-    load_rot(q0 + l15, qf);
+    // the second rotary's table rows (position t + 1) are fetched now: their latency hides under everything below
+    const int pos2 = q0 + (l15 < window ? l15 : window - 1) + 1;
+    f32x4 c2[NNB / 2], s2[NNB / 2];
+#pragma unroll
+    for (int nb = 0; nb < NNB / 2; ++nb) {
+        c2[nb] = *reinterpret_cast<const f32x4*>(cosT + (long)pos2 * HALF + 16 * nb + 4 * lq);
+        s2[nb] = *reinterpret_cast<const f32x4*>(sinT + (long)pos2 * HALF + 16 * nb + 4 * lq);
+    }
     // park the rotated key rows for the transposed V reads
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb)
@@ -591,6 +598,15 @@ __global__ __launch_bounds__(256) void local_attention_h_kernel(const half_t* __
             const int row = kb * 16 + l15;
             *reinterpret_cast<la_f16x8*>(sm + row * ROWB + (((ks * 4 + lq) ^ fswz(row)) << 4)) = kf[kb][ks];
         }
+    // the queries ARE key rows q0 - k0 .. (rotated at the same positions): read back from the parked rows instead of
+    // loading and rotating them a second time (rows past the window belong to lanes whose output is not stored)
+    __builtin_amdgcn_s_waitcnt(0xc07f);               // the wave's own LDS writes (no other wave touches its region)
+    {
+        const int row = q0 - k0 + l15;                // <= 25 < 32
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks)
+            qf[ks] = *reinterpret_cast<const la_f16x8*>(sm + row * ROWB + (((ks * 4 + lq) ^ fswz(row)) << 4));
+    }
     // S^T[key][query]
     f32x4 s[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
@@ -623,7 +639,6 @@ __global__ __launch_bounds__(256) void local_attention_h_kernel(const half_t* __
     const float inv = 1.0f / sum;
     const la_f16x8 pf = la_f16x8{(half_t)(v[0] * inv), (half_t)(v[1] * inv), (half_t)(v[2] * inv), (half_t)(v[3] * inv),
                                  (half_t)(v[4] * inv), (half_t)(v[5] * inv), (half_t)(v[6] * inv), (half_t)(v[7] * inv)};
-    __builtin_amdgcn_s_waitcnt(0xc07f);               // the wave's own LDS writes (no other wave touches its region)
     // O^T[hd][query] += V^T P^T
     const int vrow = 4 * lq + (l15 >> 2);
     const int vbase = vrow * ROWB + ((fswz(vrow) >> 1) << 5) + (l15 & 3) * 8;
@@ -642,8 +657,7 @@ __global__ __launch_bounds__(256) void local_attention_h_kernel(const half_t* __
         const long orow = ((long)b * (T + 1) + pos) * d + head * E;
 #pragma unroll
         for (int nb = 0; nb < NNB / 2; ++nb) {
-            const f32x4 c = *reinterpret_cast<const f32x4*>(cosT + (long)pos * HALF + 16 * nb + 4 * lq);
-            const f32x4 sn = *reinterpret_cast<const f32x4*>(sinT + (long)pos * HALF + 16 * nb + 4 * lq);
+            const f32x4 c = c2[nb], sn = s2[nb];
             const f32x4 lo = o[nb], hi = o[nb + NNB / 2];
             const f32x4 rl = lo * c - hi * sn, rh = hi * c + lo * sn;
             *reinterpret_cast<f16x4*>(enc16 + orow + 16 * nb + 4 * lq) = f16x4{(half_t)rl[0], (half_t)rl[1], (half_t)rl[2], (half_t)rl[3]};
