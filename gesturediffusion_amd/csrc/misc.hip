@@ -505,10 +505,151 @@ __global__ __launch_bounds__(64) void local_attention_kernel(const float* __rest
     }
 }
 
+// The same front end on the fp32 MFMA (v_mfma_f32_16x16x4_f32), one wave per (sample, local head, window), four waves per
+// block -- the structure of local_attention_h_kernel below with fp32 fragments:
+//   * a lane loads float4 pieces of "its" row (row l15 of a 16-row block, head-dim 16kk + 4lq .. +3), so both halves of a
+//     rotary pair sit in the same lane; the rotated pieces are directly the fragments of S^T = K Q^T (k-slot lq of k-step
+//     (kk, e) <-> head-dim 16kk + 4lq + e, the same map for both operands);
+//   * the rotated key rows are parked in LDS (row stride E + 4 floats: the four k-slots of a V^T fragment read land 16
+//     banks apart); the queries ARE key rows q0 - k0 .., read back from there;
+//   * softmax on the accumulator layout (query on the lane axis, keys 4lq + r in the registers): register r of the
+//     probability tile is the B operand of the PV k-step whose slot lq holds key 4lq + r -- no cross-lane movement;
+//   * second rotary (position t + 1) on the O^T accumulators, in-lane; float4 stores into the encoder input.
+// The scalar kernel above spends its time in ~1 000 four-byte LDS reads per lane (87 us at config 2's V2 shape).
+template <int E>
+__global__ __launch_bounds__(256) void local_attention_mfma_kernel(const float* __restrict__ xseq,
+                                                                   const float* __restrict__ cosT,
+                                                                   const float* __restrict__ sinT, float* __restrict__ enc,
+                                                                   half_t* __restrict__ enc16, int nwork, int T, int d,
+                                                                   int heads, int window) {
+    constexpr int HALF = E / 2, NKK = E / 16, NNB = E / 16, RS = E + 4;
+    __shared__ __attribute__((aligned(16))) float sm_all[4 * 32 * RS];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int l15 = lane & 15, lq = lane >> 4;
+    int work = blockIdx.x * 4 + wave;
+    const bool active = work < nwork;
+    work = active ? work : nwork - 1;                 // surplus waves redo the last window and skip the stores
+    float* sm = sm_all + wave * 32 * RS;
+    const int nwin = T / window;
+    const int w = work % nwin, head = (work / nwin) % heads, b = work / (nwin * heads);
+    const int k0 = w == 0 ? 0 : (w - 1) * window;
+    const int q0 = w * window;
+    const int nkeys = q0 + window - k0;               // window or 2*window (<= 32)
+    const float* xb = xseq + ((long)b * T) * d + head * E;
+
+    auto load_rot = [&](int pos, f32x4 (&f)[NKK]) {   // rows past the sequence read row T-1 (masked below)
+        const int pc = pos < T ? pos : T - 1;
+        const float* row = xb + (long)pc * d + 4 * lq;
+#pragma unroll
+        for (int kk = 0; kk < NKK; ++kk) f[kk] = *reinterpret_cast<const f32x4*>(row + 16 * kk);
+#pragma unroll
+        for (int kk = 0; kk < NKK / 2; ++kk) {
+            const f32x4 c = *reinterpret_cast<const f32x4*>(cosT + (long)pc * HALF + 16 * kk + 4 * lq);
+            const f32x4 sn = *reinterpret_cast<const f32x4*>(sinT + (long)pc * HALF + 16 * kk + 4 * lq);
+            const f32x4 lo = f[kk], hi = f[kk + NKK / 2];
+            f[kk] = lo * c - hi * sn;
+            f[kk + NKK / 2] = hi * c + lo * sn;
+        }
+    };
+    f32x4 kf[2][NKK], qf[NKK];
+    load_rot(k0 + l15, kf[0]);
+    load_rot(k0 + 16 + l15, kf[1]);
+    const int pos2 = q0 + (l15 < window ? l15 : window - 1) + 1;      // the second rotary's table rows, fetched up front
+    f32x4 c2[NNB / 2], s2[NNB / 2];
+#pragma unroll
+    for (int nb = 0; nb < NNB / 2; ++nb) {
+        c2[nb] = *reinterpret_cast<const f32x4*>(cosT + (long)pos2 * HALF + 16 * nb + 4 * lq);
+        s2[nb] = *reinterpret_cast<const f32x4*>(sinT + (long)pos2 * HALF + 16 * nb + 4 * lq);
+    }
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int kk = 0; kk < NKK; ++kk)
+            *reinterpret_cast<f32x4*>(sm + (kb * 16 + l15) * RS + 16 * kk + 4 * lq) = kf[kb][kk];
+    __builtin_amdgcn_s_waitcnt(0xc07f);               // the wave's own LDS writes (no other wave touches its region)
+#pragma unroll
+    for (int kk = 0; kk < NKK; ++kk) qf[kk] = *reinterpret_cast<const f32x4*>(sm + (q0 - k0 + l15) * RS + 16 * kk + 4 * lq);
+    // S^T[key][query]: lane (query l15, quad lq), register r <-> key 16kb + 4lq + r
+    f32x4 s[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+    for (int kk = 0; kk < NKK; ++kk)
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) s[kb] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[kb][kk][e], qf[kk][e], s[kb], 0, 0, 0);
+    const float scale = 1.0f / sqrtf((float)E);
+    float v[8];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int kk = kb * 16 + 4 * lq + r;
+            float x = s[kb][r] * scale;
+            if (kk >= nkeys || k0 + kk > q0 + l15) x = -INFINITY;     // look-back padding / causal
+            v[kb * 4 + r] = x;
+            mx = fmaxf(mx, x);
+        }
+    mx = fmaxf(mx, __shfl_xor(mx, 16));
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    float sum = 0.0f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        v[j] = expf(v[j] - mx);
+        sum += v[j];
+    }
+    sum += __shfl_xor(sum, 16);
+    sum += __shfl_xor(sum, 32);
+    const float inv = 1.0f / sum;
+    // O^T[hd][query] = V^T P^T: k-step (kb, r), slot lq <-> key 16kb + 4lq + r
+    f32x4 o[NNB];
+#pragma unroll
+    for (int nb = 0; nb < NNB; ++nb) o[nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float pr = v[kb * 4 + r] * inv;
+            const float* vr = sm + (kb * 16 + 4 * lq + r) * RS + l15;
+#pragma unroll
+            for (int nb = 0; nb < NNB; ++nb) o[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(vr[16 * nb], pr, o[nb], 0, 0, 0);
+        }
+    // second rotary at position t+1 (lane: query l15, head-dim 16nb + 4lq + r; partner block nb +- NNB/2), store
+    if (active && l15 < window) {
+        const int pos = q0 + l15 + 1;
+        const long orow = ((long)b * (T + 1) + pos) * d + head * E;
+#pragma unroll
+        for (int nb = 0; nb < NNB / 2; ++nb) {
+            const f32x4 c = c2[nb], sn = s2[nb];
+            const f32x4 lo = o[nb], hi = o[nb + NNB / 2];
+            const f32x4 rl = lo * c - hi * sn, rh = hi * c + lo * sn;
+            *reinterpret_cast<f32x4*>(enc + orow + 16 * nb + 4 * lq) = rl;
+            *reinterpret_cast<f32x4*>(enc + orow + 16 * (nb + NNB / 2) + 4 * lq) = rh;
+            if (enc16) {
+                typedef half_t h4 __attribute__((ext_vector_type(4)));
+                *reinterpret_cast<h4*>(enc16 + orow + 16 * nb + 4 * lq) = h4{(half_t)rl[0], (half_t)rl[1], (half_t)rl[2], (half_t)rl[3]};
+                *reinterpret_cast<h4*>(enc16 + orow + 16 * (nb + NNB / 2) + 4 * lq) = h4{(half_t)rh[0], (half_t)rh[1], (half_t)rh[2], (half_t)rh[3]};
+            }
+        }
+    }
+}
+
 hipError_t launch_local_attention(const float* xseq, const float* cosT, const float* sinT, float* enc,
                                   _Float16* enc16_, int B, int T, int d, int heads, int window, hipStream_t s) {
     half_t* enc16 = reinterpret_cast<half_t*>(enc16_);
     const int e = d / heads;
+    static const bool scalar_only = getenv("GDX_LOCAL_ATTN_SCALAR") != nullptr;      // A/B switch
+    if (!scalar_only && (e == 32 || e == 64 || e == 128) && window >= 1 && window <= 16 && d % 4 == 0) {
+        const int nwork = B * heads * (T / window);
+        const dim3 grid((nwork + 3) / 4), block(256);
+        if (e == 128)
+            hipLaunchKernelGGL(local_attention_mfma_kernel<128>, grid, block, 0, s, xseq, cosT, sinT, enc, enc16, nwork, T, d, heads, window);
+        else if (e == 64)
+            hipLaunchKernelGGL(local_attention_mfma_kernel<64>, grid, block, 0, s, xseq, cosT, sinT, enc, enc16, nwork, T, d, heads, window);
+        else
+            hipLaunchKernelGGL(local_attention_mfma_kernel<32>, grid, block, 0, s, xseq, cosT, sinT, enc, enc16, nwork, T, d, heads, window);
+        return hipGetLastError();
+    }
     const size_t lds = (size_t)(2 * window * (e + 1) + window * 2 * window + window * (e + 1)) * sizeof(float);
     const dim3 grid(B * heads * (T / window)), block(64);
     hipLaunchKernelGGL(local_attention_kernel, grid, block, lds, s, xseq, cosT, sinT, enc, enc16, T, d, heads, window);

@@ -275,10 +275,13 @@ def test_real_shapes_vs_reference_golden(name, arch, J, dm):
 
 
 @pytest.mark.parametrize("arch,dm,H,T,B", [("mdm_old", 256, 4, 37, 3), ("mdm", 256, 4, 40, 2), ("mdm_old", 512, 4, 15, 5),
-                                            ("mdm_old", 128, 2, 250, 1), ("mdm", 512, 8, 30, 2)])
+                                            ("mdm_old", 128, 2, 250, 1), ("mdm", 512, 8, 30, 2), ("mdm", 1024, 4, 20, 2),
+                                            ("mdm", 512, 4, 10, 3), ("mdm", 256, 4, 70, 5)])
 def test_forward_vs_oracle_odd_shapes(arch, dm, H, T, B):
     """Shapes outside the fixtures: head_dim 64 (attention2's second instantiation), sequences that are
-    not multiples of the 16/32-token blocks, a single sample, 8 heads, K = 263+ tails -- against the CPU oracle."""
+    not multiples of the 16/32-token blocks, a single sample, 8 heads, K = 263+ tails -- against the CPU oracle.  The V2
+    rows run the fp32-MFMA local-attention front end at its three head widths (d / 8 = 32, 64, 128), with one window
+    only (T = 10), and with a work count that is not a multiple of the four waves of a block (5 x 8 x 7 windows)."""
     from gesturediffusion_amd.utils.init import init_state_dict, synthetic_inputs
     from oracle import mdm_forward as omf
     cfg = dict(arch=arch, njoints=37, nfeats=1, latent_dim=dm, ff_size=192, num_layers=2, num_heads=H, seed_poses=10)
