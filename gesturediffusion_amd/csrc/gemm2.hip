@@ -406,7 +406,7 @@ static hipError_t launch_cfg(const GemmParams& p, int epi, int omode, int num_cu
 
 // (MB, NBW, BK, NST): tile = 16*MB x 64*NBW, K slab BK, NST LDS stages (validity incl. the N-float bias copy is checked per problem).
 #define G4_CONFIGS(X) \
-    X(4, 2, 32, 4) X(5, 2, 32, 4) X(6, 2, 32, 4) X(8, 2, 32, 3) X(9, 2, 32, 3) X(5, 3, 32, 3) X(4, 3, 32, 3) X(4, 1, 64, 3) X(5, 1, 64, 3) X(4, 1, 32, 4) X(5, 1, 32, 4) X(8, 1, 32, 4) X(9, 1, 32, 4)
+    X(4, 2, 32, 4) X(5, 2, 32, 4) X(6, 2, 32, 4) X(8, 2, 32, 3) X(9, 2, 32, 3) X(5, 3, 32, 3) X(4, 3, 32, 3) X(4, 1, 64, 3) X(5, 1, 64, 3) X(4, 1, 32, 4) X(5, 1, 32, 4) X(8, 1, 32, 4) X(9, 1, 32, 4) X(2, 1, 64, 3) X(1, 1, 64, 3)
 
 static bool g4_valid(int mb, int nbw, int bk, int nst, const GemmParams& p) {
     const size_t rowb = (size_t)(bk + 8) * 4;
