@@ -20,7 +20,7 @@ EXPORTS = [
     "gdx_create", "gdx_destroy", "gdx_last_error", "gdx_set_weight", "gdx_weights_ready", "gdx_prepare",
     "gdx_set_condition", "gdx_forward", "gdx_set_keep_taps", "gdx_get_tap", "gdx_sampler_update", "gdx_q_sample",
     "gdx_randn", "gdx_sample_loop", "gdx_bench_ffn_gemm", "gdx_bench_gemm", "gdx_forward_flops", "gdx_profile_begin", "gdx_profile_end", "gdx_bench_attention",
-    "gdx_linear_f16", "gdx_bench_gemm_f16", "gdx_attention_f16", "gdx_attention_f32", "gdx_plms_update", "gdx_postprocess", "gdx_q_sample_t", "gdx_masked_l2", "gdx_set_graph_replay", "gdx_mfcc",
+    "gdx_linear_f16", "gdx_linear_f32", "gdx_bench_gemm_f16", "gdx_attention_f16", "gdx_attention_f32", "gdx_plms_update", "gdx_postprocess", "gdx_q_sample_t", "gdx_masked_l2", "gdx_set_graph_replay", "gdx_mfcc",
     "gdx_set_guards", "gdx_check_guards", "gdx_packed_bytes", "gdx_export_packed", "gdx_import_packed", "gdx_set_test_half_dtype",
 ]
 
@@ -104,6 +104,7 @@ def load():
         "gdx_bench_gemm": [i32, i32, i32, i32, i32, C.POINTER(C.c_float), vp],
         "gdx_bench_attention": [i32, i32, i32, i32, i32, i32, C.POINTER(C.c_float), vp],
         "gdx_linear_f16": [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp],
+        "gdx_linear_f32": [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp],
         "gdx_set_graph_replay": [vp, i32],
         "gdx_mfcc": [vp, i64, i32, i32, i32, i32, i32, i32, C.c_float, vp, vp, vp, vp, vp, vp, vp, vp, vp],
         "gdx_q_sample_t": [vp, vp, vp, vp, i32, i64, vp, vp],

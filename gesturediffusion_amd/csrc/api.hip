@@ -1250,6 +1250,47 @@ extern "C" int gdx_bench_gemm(int32_t M, int32_t N, int32_t K, int32_t epi, int3
     return 0;
 }
 
+namespace gdx { extern int g2_test_tile[3]; }
+
+// out = epilogue(A W^T) through the fp32 GEMM path of the encoder (csrc/gemm2.hip, fallback gemm.hip) on padded scratch
+// copies of the caller's arrays (test entry point: the kernels read / store whole tiles past M, like the workspace).
+extern "C" int gdx_linear_f32(const float* A, const float* W, const float* bias, const float* R, float* C, int32_t M,
+                              int32_t N, int32_t K, int32_t epi, int32_t tile_mb, int32_t tile_nbw, int32_t tile_bk,
+                              void* stream) {
+    if (!A || !W || !C || M <= 0 || N <= 0 || K <= 0 || K % 32 || epi < EPI_BIAS || epi > EPI_RES || (epi == EPI_RES && !R))
+        return fail("gdx_linear_f32: bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    hipError_t e = gemm_init();
+    if (e != hipSuccess) return fail(std::string("gemm_init: ") + hipGetErrorString(e));
+    const int npad = round_up(N, 128);
+    float *a = nullptr, *w = nullptr, *b = nullptr, *r = nullptr, *c = nullptr;
+    std::vector<void*> pool;
+    const size_t prow = (size_t)M + GDX_ROW_PAD;
+    int rc = 0;
+    if (dev_alloc(pool, (void**)&a, sizeof(float) * prow * K) || dev_alloc(pool, (void**)&w, sizeof(float) * (size_t)npad * K) ||
+        dev_alloc(pool, (void**)&b, sizeof(float) * npad) || dev_alloc(pool, (void**)&r, sizeof(float) * prow * N) ||
+        dev_alloc(pool, (void**)&c, sizeof(float) * prow * N))
+        rc = -1;
+    if (!rc && (hipMemsetAsync(a, 0, sizeof(float) * prow * K, s) != hipSuccess || hipMemsetAsync(w, 0, sizeof(float) * (size_t)npad * K, s) != hipSuccess ||
+                hipMemsetAsync(b, 0, sizeof(float) * npad, s) != hipSuccess || hipMemsetAsync(r, 0, sizeof(float) * prow * N, s) != hipSuccess ||
+                hipMemcpyAsync(a, A, sizeof(float) * (size_t)M * K, hipMemcpyDeviceToDevice, s) != hipSuccess ||
+                hipMemcpyAsync(w, W, sizeof(float) * (size_t)N * K, hipMemcpyDeviceToDevice, s) != hipSuccess ||
+                (bias && hipMemcpyAsync(b, bias, sizeof(float) * N, hipMemcpyDeviceToDevice, s) != hipSuccess) ||
+                (R && hipMemcpyAsync(r, R, sizeof(float) * (size_t)M * N, hipMemcpyDeviceToDevice, s) != hipSuccess)))
+        rc = fail("gdx_linear_f32: staging failed");
+    if (!rc) {
+        GemmParams p{a, K, w, K, b, epi == EPI_RES ? r : nullptr, N, nullptr, 0, c, N, M, N, K, 1, 1};
+        g2_test_tile[0] = tile_mb; g2_test_tile[1] = tile_nbw; g2_test_tile[2] = tile_bk;
+        rc = gemm(A_ROWS, B_WEIGHT, OUT_ROWS, epi, p, s);
+        g2_test_tile[0] = g2_test_tile[1] = g2_test_tile[2] = 0;
+    }
+    if (!rc && hipMemcpyAsync(C, c, sizeof(float) * (size_t)M * N, hipMemcpyDeviceToDevice, s) != hipSuccess)
+        rc = fail("gdx_linear_f32: copy-out failed");
+    (void)hipStreamSynchronize(s);
+    free_pool(pool);
+    return rc;
+}
+
 extern "C" int gdx_set_test_half_dtype(int32_t dtype) {
     if (dtype != GDX_DTYPE_F16 && dtype != GDX_DTYPE_BF16) return fail("gdx_set_test_half_dtype: GDX_DTYPE_F16 or GDX_DTYPE_BF16");
     g_test_bf16 = dtype == GDX_DTYPE_BF16;

@@ -372,6 +372,7 @@ __global__ __launch_bounds__(512, 1) void gemm4_kernel(const GemmParams p, const
 }
 
 unsigned long long* g2_dbg_buf = nullptr;   // set by gdx_bench_gemm when GDX_GEMM_DEBUG is set
+int g2_test_tile[3] = {0, 0, 0};            // (MB, NBW, BK) forced by gdx_linear_f32 for the duration of one call (tests)
 
 template <int MB, int NBW, int BK, int NST>
 constexpr size_t g4_lds_bytes(int N) {
@@ -455,11 +456,13 @@ hipError_t launch_gemm2(int omode, int epi, const GemmParams& p, hipStream_t s) 
         if (const char* e = getenv("GDX_GEMM_TILE")) sscanf(e, "%d,%d,%d", &force_mb, &force_nbw, &force_bk);
     }
     static const bool debug = getenv("GDX_GEMM_DEBUG") != nullptr;
+    const int f_mb = g2_test_tile[0] ? g2_test_tile[0] : force_mb, f_nbw = g2_test_tile[0] ? g2_test_tile[1] : force_nbw,
+              f_bk = g2_test_tile[0] ? g2_test_tile[2] : force_bk;     // gdx_linear_f32's tile argument wins over the environment
     double best = 1e30;
 #define X(mb, nbw, bk, nst)                                                                       \
     if (g4_valid(mb, nbw, bk, nst, p)) {                                                               \
         double c = g4_cost(mb, nbw, bk, p.M, p.N, p.K, num_cus);                                  \
-        if (force_mb == mb && force_nbw == nbw && force_bk == bk) c = 0.0;                        \
+        if (f_mb == mb && f_nbw == nbw && f_bk == bk) c = 0.0;                                    \
         if (c < best) { best = c; best_mb = mb; best_nbw = nbw; best_bk = bk; }                   \
     }
     G4_CONFIGS(X)

@@ -316,6 +316,13 @@ int gdx_set_test_half_dtype(int32_t dtype);
  * a padded scratch copy and synchronises the stream. */
 int gdx_attention_f32(const float* qkv, float* ctx, int32_t B, int32_t S, int32_t H, int32_t d, int32_t version,
                       void* stream);
+/* C = epilogue(A W^T) through the fp32 GEMM of the encoder projections (csrc/gemm2.hip; the nn.Linear calls of
+ * model/mdm.py:90-96,350-356,372-380): A [M][K], W [N][K], bias [N] or NULL, R [M][N] (epi 2) fp32 device arrays, C [M][N].
+ * epi 0 = + bias, 1 = gelu(. + bias), 2 = + bias + R.  K % 32 == 0.  (tile_mb, tile_nbw, tile_bk) != 0 forces that tile
+ * shape of the persistent kernel (16*mb rows x 64*nbw columns, K slab bk) instead of the cost model's choice.  Test entry
+ * point: works on padded scratch copies and synchronises the stream. */
+int gdx_linear_f32(const float* A, const float* W, const float* bias, const float* R, float* C, int32_t M, int32_t N,
+                   int32_t K, int32_t epi, int32_t tile_mb, int32_t tile_nbw, int32_t tile_bk, void* stream);
 /* Time `iters` launches of the fp16 GEMM on scratch operands filled with N(0,1). */
 int gdx_bench_gemm_f16(int32_t M, int32_t N, int32_t K, int32_t gelu, int32_t iters, float* avg_us,
                        void* stream);

@@ -663,3 +663,34 @@ def test_generate_two_ranks_equal_one_rank(tmp_path):
     assert a.shape == b.shape == (5, 37, 1, 40) and np.array_equal(a, b)
     with pytest.raises(ValueError):
         generate.resolve_rng("torch", 2)
+
+
+G4_TILES = [(4, 2, 32), (5, 2, 32), (6, 2, 32), (8, 2, 32), (9, 2, 32), (5, 3, 32), (4, 3, 32), (4, 1, 64), (5, 1, 64), (4, 1, 32),
+            (5, 1, 32), (8, 1, 32), (9, 1, 32), (2, 1, 64), (1, 1, 64)]
+
+
+@pytest.mark.parametrize("tile", G4_TILES + [(0, 0, 0)])
+def test_fp32_gemm_every_tile_shape_vs_torch(tile):
+    """The persistent fp32 GEMM (csrc/gemm2.hip) alone, every tile shape of G4_CONFIGS forced in turn (and the cost model's
+    own choice): plain, GELU and residual epilogues (the residual one is the RESP instantiation where the shape has one),
+    row counts of one row, less than a tile, a ragged last tile and several rounds of tiles, against fp64 torch."""
+    import ctypes as C
+    from gesturediffusion_amd import _lib
+    lib = _lib.load()
+    d = dev()
+    mb, nbw, bk = tile
+    N = 64 * (nbw or 2) * 3
+    K = (bk or 32) * 6
+    s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    vp = lambda t: C.c_void_p(t.data_ptr())
+    for M in (1, 77, 16 * (mb or 5) * 3 + 5, 3000 if mb <= 2 else 16 * mb * 300 + 11):
+        g = torch.Generator(device=d).manual_seed(M + 7 * mb + nbw)
+        A = torch.randn(M, K, device=d, generator=g)
+        W = torch.randn(N, K, device=d, generator=g) / K ** 0.5
+        b = torch.randn(N, device=d, generator=g)
+        R = torch.randn(M, N, device=d, generator=g)
+        lin = A.double() @ W.double().t() + b.double()
+        for epi, ref in ((0, lin), (1, torch.nn.functional.gelu(lin)), (2, lin + R.double())):
+            out = torch.full((M, N), float("nan"), device=d)
+            _lib.check(lib.gdx_linear_f32(vp(A), vp(W), vp(b), vp(R), vp(out), M, N, K, epi, mb, nbw, bk, s), lib)
+            assert rel_err(out.cpu().double(), ref.cpu()) < 3e-6, (tile, M, epi)
