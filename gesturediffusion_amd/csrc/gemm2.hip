@@ -116,9 +116,11 @@ __global__ __launch_bounds__(512, 1) void gemm4_kernel(const GemmParams p, const
     constexpr int PW = (P + 3) / 4;                           // pieces per wave per slab
     constexpr int KK = BK / 16;                               // 16-deep fragment groups per slab
     constexpr int NSTORE = MB * NBW * 4;                      // epilogue store instructions per wave per tile
-    constexpr int VM_STEP = (NST - 3) * PW;                   // DMA pieces younger than the slab a step must wait for
+    constexpr int VM_STEP = NST >= 3 ? (NST - 3) * PW : 0;    // DMA pieces younger than the slab a step must wait for
     static_assert(W_BYTES == BN * ROWB, "W region must have no gap (rows past N are not padded)");
-    static_assert(NST >= 3, "ring needs >= 3 stages (fragments of slab g+1 are read during step g)");
+    // NST == 2 (64-deep slabs of the widest tiles, which do not fit three times): slab g+1 lands DURING step g, so the first
+    // fragment group of a step is read after the step's barrier instead of across it
+    static_assert(NST >= 2, "ring needs >= 2 stages");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* const bias_lds = reinterpret_cast<float*>(smem + NST * STAGE_BYTES);
 
@@ -267,9 +269,9 @@ __global__ __launch_bounds__(512, 1) void gemm4_kernel(const GemmParams p, const
             mm(fa0, fb0);
             interleave();
         }
-        rd(fa0, fb0, nstage, 0);                              // next slab's first group: landed before the last barrier
+        if constexpr (NST >= 3) rd(fa0, fb0, nstage, 0);      // next slab's first group: landed before the last barrier
         mm(fa1, fb1);                                         // (past the last slab: a stale stage, never used)
-        interleave();
+        if constexpr (NST >= 3) interleave();
         if (++ks == nk) {
             ks = 0;
             // ---- epilogue straight from the accumulators.  The MFMA runs swapped (weight fragment = A operand), so a
@@ -362,6 +364,7 @@ __global__ __launch_bounds__(512, 1) void gemm4_kernel(const GemmParams p, const
         // the loaders have waited for slab g+2 before this barrier; step g+1 prefetches from it
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         stage = nstage;
+        if constexpr (NST == 2) rd(fa0, fb0, stage, 0);       // the slab that landed during the step
     }
     if (dbg && blockIdx.x == 0 && tid == 0) {                 // diagnostic stamps (gdx_bench_gemm + GDX_GEMM_DEBUG)
         dbg[0] = __builtin_amdgcn_s_memtime() - t0;
@@ -406,8 +409,12 @@ static hipError_t launch_cfg(const GemmParams& p, int epi, int omode, int num_cu
 }
 
 // (MB, NBW, BK, NST): tile = 16*MB x 64*NBW, K slab BK, NST LDS stages (validity incl. the N-float bias copy is checked per problem).
+// The NST = 2 shapes (round 2) are the 128- and 192-column tiles with 64-deep slabs -- one barrier per 64 instead of per 32 deep,
+// for a first fragment group read after the barrier instead of across it: FFN-1's shape 110.8 -> 108.1 us, QKV's 153.6 -> 152.0.
+// With a single slab in flight they are not offered to the epilogues that load a residual / hoisted term (p.R): those loads delay
+// the slab (M = 12 864, 144x64: 116 -> 124 us).
 #define G4_CONFIGS(X) \
-    X(4, 2, 32, 4) X(5, 2, 32, 4) X(6, 2, 32, 4) X(8, 2, 32, 3) X(9, 2, 32, 3) X(5, 3, 32, 3) X(4, 3, 32, 3) X(4, 1, 64, 3) X(5, 1, 64, 3) X(4, 1, 32, 4) X(5, 1, 32, 4) X(8, 1, 32, 4) X(9, 1, 32, 4) X(2, 1, 64, 3) X(1, 1, 64, 3)
+    X(4, 2, 32, 4) X(5, 2, 32, 4) X(6, 2, 32, 4) X(8, 2, 32, 3) X(9, 2, 32, 3) X(5, 3, 32, 3) X(4, 3, 32, 3) X(4, 1, 64, 3) X(5, 1, 64, 3) X(4, 1, 32, 4) X(5, 1, 32, 4) X(8, 1, 32, 4) X(9, 1, 32, 4) X(2, 1, 64, 3) X(1, 1, 64, 3) X(5, 2, 64, 2) X(5, 3, 64, 2) X(4, 2, 64, 2) X(6, 2, 64, 2) X(8, 2, 64, 2) X(4, 3, 64, 2)
 
 static bool g4_valid(int mb, int nbw, int bk, int nst, const GemmParams& p) {
     const size_t rowb = (size_t)(bk + 8) * 4;
@@ -459,8 +466,9 @@ hipError_t launch_gemm2(int omode, int epi, const GemmParams& p, hipStream_t s) 
     const int f_mb = g2_test_tile[0] ? g2_test_tile[0] : force_mb, f_nbw = g2_test_tile[0] ? g2_test_tile[1] : force_nbw,
               f_bk = g2_test_tile[0] ? g2_test_tile[2] : force_bk;     // gdx_linear_f32's tile argument wins over the environment
     double best = 1e30;
+    static const bool no_nst2 = getenv("GDX_GEMM_NO_NST2") != nullptr;     // A/B switch: without the two-stage 64-deep shapes
 #define X(mb, nbw, bk, nst)                                                                       \
-    if (g4_valid(mb, nbw, bk, nst, p)) {                                                               \
+    if (g4_valid(mb, nbw, bk, nst, p) && !(nst == 2 && (no_nst2 || p.R))) {                            \
         double c = g4_cost(mb, nbw, bk, p.M, p.N, p.K, num_cus);                                  \
         if (f_mb == mb && f_nbw == nbw && f_bk == bk) c = 0.0;                                    \
         if (c < best) { best = c; best_mb = mb; best_nbw = nbw; best_bk = bk; }                   \

@@ -666,13 +666,15 @@ def test_generate_two_ranks_equal_one_rank(tmp_path):
 
 
 G4_TILES = [(4, 2, 32), (5, 2, 32), (6, 2, 32), (8, 2, 32), (9, 2, 32), (5, 3, 32), (4, 3, 32), (4, 1, 64), (5, 1, 64), (4, 1, 32),
-            (5, 1, 32), (8, 1, 32), (9, 1, 32), (2, 1, 64), (1, 1, 64)]
+            (5, 1, 32), (8, 1, 32), (9, 1, 32), (2, 1, 64), (1, 1, 64),
+            (5, 2, 64), (5, 3, 64), (4, 2, 64), (6, 2, 64), (8, 2, 64), (4, 3, 64)]   # the last six: two-stage rings (NST = 2)
 
 
 @pytest.mark.parametrize("tile", G4_TILES + [(0, 0, 0)])
 def test_fp32_gemm_every_tile_shape_vs_torch(tile):
     """The persistent fp32 GEMM (csrc/gemm2.hip) alone, every tile shape of G4_CONFIGS forced in turn (and the cost model's
-    own choice): plain, GELU and residual epilogues (the residual one is the RESP instantiation where the shape has one),
+    own choice): plain, GELU and residual epilogues (the residual one is the RESP instantiation where the shape has one; the
+    two-stage shapes are not offered to it and the call falls back to the cost model's choice),
     row counts of one row, less than a tile, a ragged last tile and several rounds of tiles, against fp64 torch."""
     import ctypes as C
     from gesturediffusion_amd import _lib
