@@ -171,7 +171,13 @@ __device__ __forceinline__ void sched_interleave() {
     }
 }
 
-template <int MB, int NBW, int NST>
+// PAIR (round 2): one barrier per TWO 32-deep slabs.  With 18-32 MFMAs per slab and wave (288-512 cycles) the per-slab
+// lgkmcnt wait + barrier was as long as the arithmetic (stamps at M = 8 336, tile 144x128: 693 cycles per slab against 288 of
+// MFMA issue).  The loaders then run two pairs ahead (ring of 6: the pair being read, the pair that has landed, the pair in
+// flight), and a pair's first fragment group is read after the barrier instead of across it.  The pair is staged as ONE 64-deep
+// slab of whole 128-byte lines (gemmh8b_kernel's LDS image): the half-line pieces of the 32-deep slabs bound the per-slab
+// kernel at the staging rate (17 KB per 696 cycles = 25 B/clk; tools/probe/dma_probe: 50 against 78 GB/s per CU).
+template <int MB, int NBW, int NST, bool PAIR>
 __global__ __launch_bounds__(512, 1) void gemmh_kernel(const GemmHParams p, const int ntn, const int ntiles,
                                                        unsigned long long* dbg) {
 #if defined(__HIP_DEVICE_COMPILE__)   // the host pass only needs the launch stub (buffer-resource builtins are device-only)
@@ -183,6 +189,7 @@ __global__ __launch_bounds__(512, 1) void gemmh_kernel(const GemmHParams p, cons
     constexpr int VM_STEP = (NST - 3) * PW;                       // DMA pieces younger than the slab a step waits for
     static_assert(NBW == 1 || NBW == 2 || NBW == 4, "NBW must be 1, 2 or 4");
     static_assert(NST >= 3 && VM_STEP < 64, "ring depth / vmcnt range");
+    static_assert(!PAIR || (NST == 6 && 2 * PW < 64), "the pair protocol is written for a ring of six");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* const bias_lds = reinterpret_cast<float*>(smem + NST * STAGE_BYTES);
 
@@ -245,6 +252,60 @@ __global__ __launch_bounds__(512, 1) void gemmh_kernel(const GemmHParams p, cons
                 ld_n0 = (tile % ntn) * BN;
             }
         };
+        if constexpr (PAIR) {
+            // 64-deep slabs staged as WHOLE 128-byte lines (the image of gemmh8b_kernel): a piece is 8 rows x 128 B, chunk c of
+            // row r sits at c ^ (((r >> 1) ^ (r >> 3)) & 7); three slab slots of 2 * STAGE_BYTES.
+            constexpr int P2 = (BM + BN) / 8, A_P2 = BM / 8, PW2 = (P2 + 3) / 4, A2_BYTES = BM * 128;
+            static_assert(PW2 < 64, "vmcnt range");
+            int voff2[PW2];
+#pragma unroll
+            for (int i = 0; i < PW2; ++i) {
+                int piece = (wave & 3) + 4 * i;
+                piece = piece < P2 ? piece : P2 - 1;              // surplus issues re-write the last piece (same bytes)
+                const bool isA = piece < A_P2;
+                const int r = (isA ? piece : piece - A_P2) * 8 + (lane >> 3);
+                const int sw = ((r >> 1) ^ (r >> 3)) & 7;
+                voff2[i] = r * (isA ? p.lda : p.ldw) * 2 + (((lane & 7) ^ sw) * 16);
+            }
+            const int nk2 = nk >> 1;
+            auto issue2 = [&](int slot) {
+                const int a_so = (ld_m0 * p.lda + ld_ks * 64) * 2;
+                const int w_so = (ld_n0 * p.ldw + ld_ks * 64) * 2;
+                char* sb = smem + slot * 2 * STAGE_BYTES;
+#pragma unroll
+                for (int i = 0; i < PW2; ++i) {
+                    int piece = (wave & 3) + 4 * i;
+                    piece = piece < P2 ? piece : P2 - 1;
+                    if (piece < A_P2)
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcA, (lds_ptr_t)(sb + piece * 1024), 16, voff2[i], a_so, 0, 0);
+                    else
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcW, (lds_ptr_t)(sb + A2_BYTES + (piece - A_P2) * 1024), 16,
+                                                                 voff2[i], w_so, 0, 0);
+                }
+                asm volatile("" ::: "memory");
+                if (++ld_ks == nk2) {
+                    ld_ks = 0;
+                    ++ld_tile_i;
+                    const int ti = ld_tile_i < my_tiles ? ld_tile_i : my_tiles - 1;   // past the end: harmless re-reads
+                    const int tile = lid + ti * G;
+                    ld_m0 = (tile / ntn) * BM;
+                    ld_n0 = (tile % ntn) * BN;
+                }
+            };
+            issue2(0);
+            issue2(1);
+            wait_vm_h<PW2>();                                     // slab 0 has landed
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            int wst = 2;
+            for (int g = 0; g < total; g += 2) {
+                issue2(wst);                                      // slab g/2 + 2 -> the slot of the slab consumed before the last barrier
+                wst = wst == 2 ? 0 : wst + 1;
+                wait_vm_h<PW2>();                                 // slab g/2 + 1 has landed
+                asm volatile("s_barrier" ::: "memory");
+            }
+            wait_vm_h<0>();
+            return;
+        }
 #pragma unroll
         for (int s = 0; s < NST - 1; ++s) issue(s);
         wait_vm_h<VM_STEP>();
@@ -329,6 +390,49 @@ __global__ __launch_bounds__(512, 1) void gemmh_kernel(const GemmHParams p, cons
     // while a block of 12 reads in front of the MFMAs idles the matrix pipe for ~100 cycles per step).
     auto interleave = [&]() { sched_interleave<0, MB + NBW, MB * NBW>(); };
     step_sync();                                                  // slabs 0 and 1 landed (loaders waited)
+    if constexpr (PAIR) {
+        constexpr int A2_BYTES = BM * 128;
+        // A row 16 i + l15: swizzle ((l15 >> 1) & 7) ^ (l15 >> 3) ^ (2 i & 7); chunk of k-step h: 4 h + lq -> lane part ^ an even
+        // constant, four offsets cover every read.  W row r_j = wave WN + (l15 >> 2) QS + (l15 & 3) + blk(j): swizzle at run time.
+        const int laneA = lq ^ ((l15 >> 1) & 7) ^ (l15 >> 3);
+        int offA[4], offW[NBW][2];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) offA[k] = l15 * 128 + ((laneA ^ (2 * k)) << 4);
+#pragma unroll
+        for (int j = 0; j < NBW; ++j) {
+            const int r = wave * WN + (l15 >> 2) * ColMap<NBW>::QS + (l15 & 3) + ColMap<NBW>::blk(j);
+            const int sw = ((r >> 1) ^ (r >> 3)) & 7;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) offW[j][h] = A2_BYTES + r * 128 + (((4 * h + lq) ^ sw) << 4);
+        }
+        auto rd2 = [&](f16x8 (&fa)[MB], f16x8 (&fw)[NBW], const char* S, auto h_tag) {
+            constexpr int h = decltype(h_tag)::value;
+#pragma unroll
+            for (int j = 0; j < NBW; ++j) fw[j] = *reinterpret_cast<const f16x8*>(S + offW[j][h]);
+#pragma unroll
+            for (int i = 0; i < MB; ++i) {
+                const int K = ((4 * h) ^ ((2 * i) & 7)) >> 1;
+                fa[i] = *reinterpret_cast<const f16x8*>(S + offA[K] + i * 2048);
+            }
+        };
+        for (int g = 0; g < total; g += 2) {
+            const char* S = smem + stage * STAGE_BYTES;           // the slab landed before the last barrier
+            rd2(fa0, fw0, S, std::integral_constant<int, 0>{});
+            rd2(fa1, fw1, S, std::integral_constant<int, 1>{});
+            mm(fa0, fw0);
+            __builtin_amdgcn_sched_group_barrier(0x100, MB + NBW, 0);   // slab g's fragments first,
+            interleave();                                               // slab g+1's between slab g's MFMAs
+            mm(fa1, fw1);
+            ks += 2;
+            if (ks == nk) {
+                ks = 0;
+                epilogue();
+            }
+            step_sync();
+            stage = stage == NST - 2 ? 0 : stage + 2;
+        }
+        return;
+    }
     rd(fa0, fw0, 0);
     for (int g = 0; g < total; g += 2) {
         // ---- even step: fragments of slab g are in (fa0, fw0)
@@ -865,13 +969,13 @@ constexpr size_t gh_lds_bytes(int N) {
     return (size_t)NST * (MB * 16 + NBW * 64) * 64 + (size_t)N * 4;
 }
 
-template <int MB, int NBW, int NST>
-static hipError_t launch_cfg_h(const GemmHParams& p, int num_cus, hipStream_t s) {
+template <int MB, int NBW, int NST, bool PAIR>
+static hipError_t launch_cfg_hp(const GemmHParams& p, int num_cus, hipStream_t s) {
     constexpr int BM = MB * 16, BN = NBW * 64;
     const size_t lds = gh_lds_bytes<MB, NBW, NST>(p.N);
     static size_t attr_lds = 0;
     if (lds > attr_lds) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemmh_kernel<MB, NBW, NST>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemmh_kernel<MB, NBW, NST, PAIR>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         attr_lds = lds;
@@ -879,8 +983,15 @@ static hipError_t launch_cfg_h(const GemmHParams& p, int num_cus, hipStream_t s)
     const int ntm = (p.M + BM - 1) / BM, ntn = p.N / BN;
     const int ntiles = ntm * ntn;
     const int grid = ntiles < num_cus ? ntiles : num_cus;
-    hipLaunchKernelGGL((gemmh_kernel<MB, NBW, NST>), dim3(grid), dim3(512), lds, s, p, ntn, ntiles, g2_dbg_buf);
+    hipLaunchKernelGGL((gemmh_kernel<MB, NBW, NST, PAIR>), dim3(grid), dim3(512), lds, s, p, ntn, ntiles, g2_dbg_buf);
     return hipGetLastError();
+}
+
+template <int MB, int NBW, int NST>
+static hipError_t launch_cfg_h(const GemmHParams& p, int num_cus, hipStream_t s) {
+    static const bool no_pair = getenv("GDX_GEMMH_NOPAIR") != nullptr;   // A/B switch; the stamped diagnostic build is the per-slab one
+    if (no_pair || g2_dbg_buf) return launch_cfg_hp<MB, NBW, NST, false>(p, num_cus, s);
+    return launch_cfg_hp<MB, NBW, NST, true>(p, num_cus, s);
 }
 
 // (MB, NBW, NST): tile = 16*MB rows x 64*NBW columns, NST LDS stages of (16*MB + 64*NBW) * 64 bytes
@@ -897,7 +1008,10 @@ static bool gh_valid(int mb, int nbw, int nst, const GemmHParams& p) {
 // time follows the bytes staged per step rather than the MFMA count.
 static double gh_step_us(int mb, int nbw) {
     // measured microseconds per K step (M = 66 688, N = 1 024, K = 1 024, one run of tools/gemmh_sweep.sh; the absolute
-    // level moves ~10 % between boxes / power states, the ranking much less)
+    // level moves ~10 % between boxes / power states, the ranking much less).  The small-tile entries date from the 32-deep
+    // half-line slabs; with whole-line 64-deep slabs (round 2) those kernels run 5-21 % faster (128x256: 0.68 -> 0.57 on one
+    // box), but re-scaling the entries made the dispatcher prefer 128x256 tiles to the 256x256 kernel + row cut at config 5's
+    // N = 1 024 GEMMs, which measured slower (169.7 against 151-159 us), so the table is left as it ranks.
     static const struct { int mb, nbw; double us; } T[] = {
         {16, 4, 1.00},                                               // 256 x 256, eight MFMA waves
         {8, 4, 0.630}, {7, 4, 0.597}, {6, 4, 0.545}, {5, 4, 0.495}, {4, 4, 0.444},
