@@ -18,8 +18,12 @@ A "step" is one denoising step (one pass of the hot path -- denoiser forward [x2
 update -- over the rank's batch).  K defaults to the loop length, so the default run times exactly ONE complete loop with
 nothing extrapolated; for other K the last K steps of the schedule are timed and `value` is normalised to one loop
 (B*T / (loop_steps * seconds per step)), which `config.timed` states.  Inputs (x_T, seed poses, MFCCs) and weights are
-resident in HBM before the timed region.  N > 1: one process per GPU (torch.distributed.run), no data-path collective,
-ONE gather of the finished samples at the end, inside the timed region.
+resident in HBM before the timed region.  N > 1: one process per GPU, no data-path collective, ONE gather of the finished
+samples at the end, inside the timed region.  The ranks come either from a launcher (`python -m torch.distributed.run
+--nproc-per-node N bench.py --gpus N ...`: RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the environment) or, when
+`python bench.py --gpus N` is started plainly (no RANK in the environment), from bench.py itself: the parent starts N fresh
+children with that environment, never touches the GPU, and exits non-zero if any child did.  The record's `dist` object says
+which backend / world size / devices the ranks saw.
 
 `--seam` selects which side of the drop-in boundary drives the loop: `philox` (default; in-kernel counter-based noise),
 `torch` (the reference caller's own kwargs -- torch's generator, progress=True -- which also run inside libgdx) or
@@ -155,6 +159,37 @@ def cpu_baseline(p, cfg, sd, B, seedp, mfcc, loop_steps, budget_s, full_loops):
             "ms_per_step": sec * 1e3}
 
 
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start N fresh children (one per GPU) with the rendezvous environment of
+    torch.distributed.run and wait for them.  The parent never initialises the GPU and never re-execs; a child that fails
+    takes the others down (exact PIDs) so that nobody is left waiting in a barrier."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), GDX_BENCH_LAUNCHER="bench.py (self-spawned ranks)")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC (RCCL between processes)
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    while procs:
+        time.sleep(0.2)
+        for pr in list(procs):
+            code = pr.poll()
+            if code is None:
+                continue
+            procs.remove(pr)
+            if code != 0 and rc == 0:
+                rc = code if code > 0 else 1
+                log(f"a rank exited with code {code}: stopping the other {len(procs)}")
+                for other in procs:
+                    other.terminate()
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -175,7 +210,15 @@ def main():
     ap.add_argument("--seam", default="philox", choices=["philox", "torch", "stepwise"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU work the cpu_baseline leg may spend")
+    ap.add_argument("--save-samples", default=None, help="rank 0 writes the gathered samples of the timed run here (torch.save)")
     args = ap.parse_args()
+    if args.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus))       # before anything touches the GPU
+    # stdout carries exactly ONE line, rank 0's record: whatever libraries print there (gloo's connection banner, RCCL
+    # notices) goes to stderr instead
+    sys.stdout.flush()
+    record_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
 
     p = dict(PRESETS[args.config])
     custom = False
@@ -189,6 +232,11 @@ def main():
 
     from gesturediffusion_amd.utils import dist_util
     from gesturediffusion_amd.utils.init import synthetic_inputs
+    if p["global_batch"]:
+        try:
+            dist_util.check_world(p["batch"])
+        except ValueError as e:
+            raise SystemExit(str(e))
     rank, world, device = dist_util.init_from_env()
     if device.type != "cuda":
         raise SystemExit("bench.py needs an MI355X: the native path has no CPU fallback")
@@ -268,6 +316,15 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     assert torch.isfinite(out).all()
+    # what the ranks saw: proves which backend moved the gather and that N distinct devices took part
+    mine = {"rank": rank, "device": str(device), "name": torch.cuda.get_device_name(device),
+            "uuid": str(getattr(torch.cuda.get_device_properties(device), "uuid", ""))}
+    seen = [mine]
+    if world > 1:
+        seen = [None] * world
+        dist.all_gather_object(seen, mine)
+    if rank == 0 and args.save_samples:
+        torch.save(out.cpu(), args.save_samples)
 
     nsub = (B + sub - 1) // sub
     ms_per_step = elapsed * 1e3 / steps                  # one step over the rank's whole batch (all its sub-batches)
@@ -315,6 +372,10 @@ def main():
                           f"last {steps} steps of the {loop_steps}-step schedule; value normalised to one loop" if steps < loop_steps else
                           f"{steps} steps = {steps / loop_steps:g} loops; value normalised to one loop"),
             },
+            "dist": {"backend": dist.get_backend() if world > 1 else None, "world": world,
+                     "launcher": os.environ.get("GDX_BENCH_LAUNCHER", "torch.distributed.run" if world > 1 else "single process"),
+                     "gather": ("batch_isend_irecv into one root buffer" if world > 1 else "none (one rank)"),
+                     "ranks": seen},
             "loop_seconds": round(ms_per_step * loop_steps * 1e-3, 3),
             "frame_steps_per_sec": round(total * T / (ms_per_step * 1e-3), 1),
             "step_tflops": round(world * flops_step / (ms_per_step * 1e-3) / 1e12, 2),
@@ -336,7 +397,7 @@ def main():
             if nb != B:
                 rec["cpu_baseline"]["sample"] += f" (one sub-batch of {nb}; frames/s does not depend on the number of sub-batches)"
             rec["gpu_over_cpu"] = round(frames_per_sec / world / rec["cpu_baseline"]["value"], 1)
-        print(json.dumps(rec), flush=True)
+        print(json.dumps(rec), file=record_out, flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -87,6 +87,8 @@ struct gdx_model {
     int d, J, ff, L, H;
     bool f16 = false;                 // reduced-precision mode (GDX_DTYPE_F16 or _BF16): 16-bit MFMA operands, fp32 accumulate
     bool bf16 = false;                // ... with bf16 elements (the gdx::b16 kernels)
+    bool stream32 = false;            // 16-bit modes: the residual stream (x + sublayer(x), LayerNorm in / out) stays fp32 and
+                                      // only the GEMM / attention operands are 16-bit copies (default for bf16, see forward_core_f16)
     _Float16 *xt16 = nullptr, *xa16 = nullptr, *xb16 = nullptr, *qkv16 = nullptr, *ctx16 = nullptr, *ffb16 = nullptr,
              *emb16 = nullptr, *xc16 = nullptr, *tmp16 = nullptr, *xseq16 = nullptr;
     std::set<std::string> have;
@@ -200,6 +202,10 @@ extern "C" int gdx_create(const gdx_config_t* cfg, gdx_handle_t* out) {
     h->cfg = *cfg;
     h->f16 = cfg->compute_dtype != GDX_DTYPE_F32;
     h->bf16 = cfg->compute_dtype == GDX_DTYPE_BF16;
+    // bf16 keeps 8 significant bits: rounding the residual stream to it after every sublayer and every LayerNorm is the
+    // largest single error term of the mode, so its stream stays fp32 (GDX_STREAM32=0 / 1 overrides for A/B measurements)
+    h->stream32 = h->bf16;
+    if (const char* e = getenv("GDX_STREAM32")) h->stream32 = h->f16 && atoi(e) != 0;
     h->d = cfg->latent_dim; h->J = cfg->njoints; h->ff = cfg->ff_size; h->L = cfg->num_layers; h->H = cfg->num_heads;
     h->layers.resize(h->L);
     auto& r = h->required;
@@ -582,6 +588,7 @@ extern "C" int gdx_prepare(gdx_handle_t h, int32_t batch, int32_t frames) {
     // fp32 activation buffers of the fp32 mode (the fp16 mode keeps its stream in the *16 buffers below)
     if (!h->f16 && (A(&h->xb, N * d) || A(&h->qkv, N * 3 * d) || A(&h->ctx, N * d) || A(&h->tmp, N * d) || A(&h->ffb, N * h->ff)))
         return -1;
+    if (h->f16 && h->stream32 && (A(&h->xb, N * d) || A(&h->tmp, N * d))) return -1;   // fp32 residual stream of the 16-bit modes
     h->ldo = round_up(h->J, 64);
     const size_t NT = B2 * frames + GDX_ROW_PAD;
     if (A(&h->x0t, NT * h->ldo)) return -1;
@@ -814,7 +821,8 @@ static int forward_core_f16(gdx_model* h, const float* x, const float* temb, int
     const float* seed_emb = mode == GDX_UNCOND ? h->seed_cat + (size_t)B * d : h->seed_cat;
     const int N = Beff * S;
     const int Jp = h->in_x.kpad16;
-    float* const tap32 = h->keep_taps ? h->xa : nullptr;              // fp32 copies only for the parity taps
+    const bool s32 = h->stream32;
+    float* const tap32 = (h->keep_taps || s32) ? h->xa : nullptr;     // fp32 copy of the encoder input: parity taps / fp32 stream
     if (!tm) HIPCHK(HFN(h->bf16, launch_transpose_in_f16, x, h->xt16, Beff, B, J, T, Jp, s));   // tm: the update kernel wrote xt16
     if (h->cfg.arch == GDX_ARCH_MDM_OLD) {
         HIPCHK(HFN(h->bf16, launch_token0, temb, tstride, seed_emb, h->pe, h->xa, h->xa16, nullptr, nullptr, nullptr, state, Beff, B, S, d, s));
@@ -845,8 +853,16 @@ static int forward_core_f16(gdx_model* h, const float* x, const float* temb, int
         if (gemm_f16(h->bf16, h->xa16, d, ly.qkv, ly.qkv.bias, nullptr, 0, nullptr, 0, nullptr, 0, h->qkv16, 3 * d, N, 3 * d, T, 0, 0, s))
             return -1;
         HIPCHK(HFN(h->bf16, launch_attentionh, h->qkv16, h->ctx16, Beff, S, h->H, d, h->rows_alloc, s));
-        if (gemm_f16(h->bf16, h->ctx16, d, ly.out, ly.out.bias, nullptr, 0, nullptr, 0, nullptr, 0, h->tmp16, d, N, d, T, 0, 0, s)) return -1;
-        HIPCHK(HFN(h->bf16, launch_layernorm_f16, h->tmp16, h->xa16, ly.g1, ly.b1, h->xb16, nullptr, N, d, 0, s));
+        // x = LN1(x + out_proj(ctx)).  16-bit stream: the GEMM rounds its output to 16 bits and the LayerNorm adds the 16-bit
+        // residual; fp32 stream (s32): the GEMM epilogue adds the fp32 residual and writes fp32, the LayerNorm writes the
+        // fp32 stream plus the 16-bit copy the next GEMM reads.
+        if (s32) {
+            if (gemm_f16(h->bf16, h->ctx16, d, ly.out, ly.out.bias, h->xa, d, nullptr, 0, h->tmp, d, nullptr, 0, N, d, T, 0, 0, s)) return -1;
+            HIPCHK(HFN(h->bf16, launch_layernorm, h->tmp, nullptr, ly.g1, ly.b1, h->xb, h->xb16, N, d, 0, s));
+        } else {
+            if (gemm_f16(h->bf16, h->ctx16, d, ly.out, ly.out.bias, nullptr, 0, nullptr, 0, nullptr, 0, h->tmp16, d, N, d, T, 0, 0, s)) return -1;
+            HIPCHK(HFN(h->bf16, launch_layernorm_f16, h->tmp16, h->xa16, ly.g1, ly.b1, h->xb16, nullptr, N, d, 0, s));
+        }
         const bool stamp = h->prof && h->prof_used + 2 <= h->prof_ev.size();
         if (stamp) HIPCHK(hipEventRecord(h->prof_ev[h->prof_used], s));
         if (gemm_f16(h->bf16, h->xb16, d, ly.ff1, ly.ff1.bias, nullptr, 0, nullptr, 0, nullptr, 0, h->ffb16, h->ff, N, h->ff, T, 0, 1, s))
@@ -855,11 +871,18 @@ static int forward_core_f16(gdx_model* h, const float* x, const float* temb, int
             HIPCHK(hipEventRecord(h->prof_ev[h->prof_used + 1], s));
             h->prof_used += 2;
         }
-        if (gemm_f16(h->bf16, h->ffb16, h->ff, ly.ff2, ly.ff2.bias, nullptr, 0, nullptr, 0, nullptr, 0, h->tmp16, d, N, d, T, 0, 0, s))
-            return -1;
         const bool last = l + 1 == h->L;
-        if (!last || h->keep_taps) HIPCHK(HFN(h->bf16, launch_layernorm_f16, h->tmp16, h->xb16, ly.g2, ly.b2, h->xa16, tap32, N, d, 0, s));
-        if (last) HIPCHK(HFN(h->bf16, launch_layernorm_f16, h->tmp16, h->xb16, ly.g2, ly.b2, h->xc16, nullptr, N, d, S, s));
+        if (s32) {
+            if (gemm_f16(h->bf16, h->ffb16, h->ff, ly.ff2, ly.ff2.bias, h->xb, d, nullptr, 0, h->tmp, d, nullptr, 0, N, d, T, 0, 0, s))
+                return -1;
+            if (!last || h->keep_taps) HIPCHK(HFN(h->bf16, launch_layernorm, h->tmp, nullptr, ly.g2, ly.b2, h->xa, h->xa16, N, d, 0, s));
+            if (last) HIPCHK(HFN(h->bf16, launch_layernorm, h->tmp, nullptr, ly.g2, ly.b2, nullptr, h->xc16, N, d, S, s));
+        } else {
+            if (gemm_f16(h->bf16, h->ffb16, h->ff, ly.ff2, ly.ff2.bias, nullptr, 0, nullptr, 0, nullptr, 0, h->tmp16, d, N, d, T, 0, 0, s))
+                return -1;
+            if (!last || h->keep_taps) HIPCHK(HFN(h->bf16, launch_layernorm_f16, h->tmp16, h->xb16, ly.g2, ly.b2, h->xa16, tap32, N, d, 0, s));
+            if (last) HIPCHK(HFN(h->bf16, launch_layernorm_f16, h->tmp16, h->xb16, ly.g2, ly.b2, h->xc16, nullptr, N, d, S, s));
+        }
         if (h->keep_taps)
             HIPCHK(hipMemcpyAsync(h->taps[l + 1], h->xa, sizeof(float) * (size_t)N * d, hipMemcpyDeviceToDevice, s));
     }

@@ -79,6 +79,7 @@ def main(argv=None):
                                   "(checkpoints still load through --model_path)")
     rng = resolve_rng(args.rng, world)
     num_samples = min(args.num_samples if args.num_samples else 41, args.batch_size)
+    dist_util.check_world(num_samples, world)       # the same refusal on every rank, before any of them builds a model
     if args.dataset not in ("genea2022", "genea2023") and not args.synthetic_njoints:
         args.synthetic_njoints = 263
     args.mfcc_input = True if args.synthetic else args.mfcc_input

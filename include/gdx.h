@@ -41,8 +41,13 @@ enum { GDX_DTYPE_F32 = 0,     /* every GEMM on the exact fp32 MFMA (default; par
        GDX_DTYPE_F16 = 1,     /* fp16 MFMA operands (weights + activations), fp32 accumulate / LayerNorm statistics / softmax:
                                  BASELINE config 5's reduced-precision mode */
        GDX_DTYPE_BF16 = 2 };  /* the same mode with bf16 elements: fp32's exponent range (fp16 overflows at 65 504) for 8 instead of
-                                 11 significant bits; the same kernels compiled for __bf16 (same 2e-2 tolerance: measured 5e-3 .. 1.2e-2 against the
-                                 reference's fp32 outputs where the fp16 mode measures 0.6 .. 1.6e-3) */
+                                 11 significant bits; the same kernels compiled for __bf16.  The residual stream (x + sublayer(x),
+                                 LayerNorm in / out) stays fp32 in this mode, only the GEMM / attention operands are bf16.
+                                 Stated tolerance against the reference's fp32 outputs, both 16-bit modes: 2e-2 of max|ref| for
+                                 forwards and whole loops; under classifier-free guidance with scale s the blend (1-s) u + s c of two
+                                 forwards is held to 2e-2 * (|s| + |1-s|)  (gesturediffusion_amd/numerics.py).  Measured: fp16
+                                 <= 2.6e-3 with or without guidance; bf16 forwards <= 1.2e-2, guided + clipped loops at s <= 2.5
+                                 <= 1.6e-2 (profiles/r03a_bf16_stream32_ab.txt; with a bf16 stream they reached 2.9e-2) */
 
 enum { GDX_SAMPLER_P = 0,     /* p_sample      diffusion/gaussian_diffusion.py:496-548 */
        GDX_SAMPLER_DDIM = 1 };/* ddim_sample   diffusion/gaussian_diffusion.py:732-782 */

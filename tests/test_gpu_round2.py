@@ -698,11 +698,12 @@ def test_fp32_gemm_every_tile_shape_vs_torch(tile):
             assert rel_err(out.cpu().double(), ref.cpu()) < 3e-6, (tile, M, epi)
 
 
-@pytest.mark.parametrize("tool,n,seed", [("fuzz_forward.py", 14, 5), ("fuzz_loops.py", 14, 7)])
+@pytest.mark.parametrize("tool,n,seed", [("fuzz_forward.py", 14, 5), ("fuzz_loops.py", 14, 2)])
 def test_random_configurations_against_the_oracle(tool, n, seed):
     """A short run of the random-configuration sweeps of tools/ (forward: shapes, topologies, dtypes; loops: sampler options) in
-    the suite; the long runs are recorded in profiles/r02m_*.  (Seed 7's loop sweep has no guided bf16 case, the one combination
-    that can leave the 2e-2 band -- DESIGN 4b.)"""
+    the suite; the long runs are recorded in profiles/r02m_*, r03*.  (The loop sweep's seed 2 opens with a guided + clipped bf16
+    loop, the combination that left the unguided 2e-2 band in round 2: each case is held to the tolerance its mode STATES for its
+    guidance scale, gesturediffusion_amd/numerics.py; tests/test_gpu_round3.py runs all fifteen such cases of the round-2 sweeps.)"""
     import runpy
     import sys
     root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")

@@ -338,3 +338,29 @@ def test_bench_presets_are_the_baseline_configs():
     assert bench.PRESETS["2"]["scaling"] == "weak"          # the headline: 64 samples per GPU
     assert bench.SCHEDULE_STEPS == 1000 and bench.F32_MFMA_PEAK_TFLOPS == 157.3 and bench.F16_MFMA_PEAK_TFLOPS == 2500.0
 
+
+
+def test_bench_gpus_n_spawns_its_own_ranks_and_reports_their_failure():
+    """`python bench.py --gpus 2` started plainly (no RANK in the environment) must start two ranks itself; on a box without
+    a GPU both refuse to run (no CPU fallback) and the parent exits non-zero instead of printing a record."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(CUDA_VISIBLE_DEVICES="", HIP_VISIBLE_DEVICES="")
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "3", "--no-cpu-baseline"], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and not r.stdout.strip()
+    assert r.stderr.count("needs an MI355X") == 2 and "stopping the other" in r.stderr
+
+
+def test_too_many_ranks_is_refused_on_every_rank():
+    from gesturediffusion_amd.utils import dist_util
+    dist_util.check_world(8, 8)
+    with pytest.raises(ValueError, match="every rank needs at least one"):
+        dist_util.check_world(5, 8)
+
+
+def test_stated_tolerance_under_guidance():
+    from gesturediffusion_amd.numerics import stated_tolerance
+    assert stated_tolerance("fp16") == stated_tolerance("bf16", 1.0) == 2e-2
+    assert stated_tolerance("bf16", 2.5) == pytest.approx(8e-2) and stated_tolerance("fp32", None, loop=False) == 1e-4
+    with pytest.raises(ValueError):
+        stated_tolerance("fp8")
