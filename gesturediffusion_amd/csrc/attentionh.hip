@@ -991,10 +991,6 @@ hipError_t launch_attentionh(const _Float16* qkv, _Float16* ctx, int B, int S, i
     // B=16 (config 5's per-GPU share): 49.5 / 58.9 / 37.4;  B=64 S=197 hd=128: 23.3 / 19.9 / 18.7.  The 8 x 2 kernel needs
     // enough workgroups to fill the chip (it makes half as many), so small problems keep the older choices.
     static const char* force = getenv("GDX_ATTNH_WAVES");            // A/B switch: "4", "8", "q" (8 waves x 2 blocks) or "p" (persistent)
-    static const bool use4 = getenv("GDX_ATTNH4") != nullptr;        // the one-wave-per-SIMD kernel of attentionh4.hip
-    static const bool user = getenv("GDX_ATTNH8R") != nullptr;       // the rotated 8-wave kernel of attentionh8r.hip
-    if (user && GDX_HNS_NAME::attentionh8r_supported(S, H, d)) return GDX_HNS_NAME::launch_attentionh8r(qkv, ctx, B, S, H, d, qkv_rows, s);
-    if (use4 && GDX_HNS_NAME::attentionh4_supported(S, H, d)) return GDX_HNS_NAME::launch_attentionh4(qkv, ctx, B, S, H, d, qkv_rows, s);
     const int nqb = (S + 15) / 16;
     const long nitems = (long)B * H * ((nqb + 15) / 16);
     const int num_cus = gemm2_num_cus();

@@ -102,12 +102,6 @@ hipError_t launch_attention3(const float* qkv, float* ctx, int B, int S, int H, 
     /* reduced-precision attention (attentionh.hip): qkv / ctx in halves, head_dim 32/64/128/256, any S; qkv_rows = readable rows */ \
     bool attentionh_supported(int S, int H, int d);                                                                         \
     hipError_t launch_attentionh(const _Float16* qkv, _Float16* ctx, int B, int S, int H, int d, long qkv_rows, hipStream_t s); \
-    /* persistent 8-wave kernel with the two waves of a SIMD rotated by half a tile (attentionh8r.hip): head_dim 64..256 */ \
-    bool attentionh8r_supported(int S, int H, int d);                                                                       \
-    hipError_t launch_attentionh8r(const _Float16* qkv, _Float16* ctx, int B, int S, int H, int d, long qkv_rows, hipStream_t s); \
-    /* one-wave-per-SIMD form (attentionh4.hip): head_dim 128 / 256, S >= 96 */                                            \
-    bool attentionh4_supported(int S, int H, int d);                                                                        \
-    hipError_t launch_attentionh4(const _Float16* qkv, _Float16* ctx, int B, int S, int H, int d, long qkv_rows, hipStream_t s); \
     /* out = LayerNorm(x + res) (res may be nullptr); compact_S > 0: rows are [B, S] tokens and token 0 of every sample is  \
        dropped from the output ([B, S-1, d]); out (fp32) and out16 (half copy) are each optional */                         \
     hipError_t launch_layernorm(const float* x, const float* res, const float* gamma, const float* beta, float* out,        \
