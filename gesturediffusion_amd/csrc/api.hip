@@ -203,9 +203,8 @@ extern "C" int gdx_create(const gdx_config_t* cfg, gdx_handle_t* out) {
     h->f16 = cfg->compute_dtype != GDX_DTYPE_F32;
     h->bf16 = cfg->compute_dtype == GDX_DTYPE_BF16;
     // bf16 keeps 8 significant bits: rounding the residual stream to it after every sublayer and every LayerNorm is the
-    // largest single error term of the mode, so its stream stays fp32 (GDX_STREAM32=0 / 1 overrides for A/B measurements)
-    h->stream32 = h->bf16;
-    if (const char* e = getenv("GDX_STREAM32")) h->stream32 = h->f16 && atoi(e) != 0;
+    // largest single error term of the mode, so its stream stays fp32
+    h->stream32 = h->bf16;                                        // A/B record: profiles/r03a_bf16_stream32_ab.txt
     h->d = cfg->latent_dim; h->J = cfg->njoints; h->ff = cfg->ff_size; h->L = cfg->num_layers; h->H = cfg->num_heads;
     h->layers.resize(h->L);
     auto& r = h->required;
@@ -390,7 +389,19 @@ extern "C" int gdx_weights_ready(gdx_handle_t h) {
 namespace {
 struct PackRec { int32_t id, n, k, npad, kpad, npad16, kpad16, pad; int64_t bytes; };
 struct PackHdr { char magic[8]; gdx_config_t cfg; int32_t nrec, pad; };
-const char PACK_MAGIC[8] = {'G', 'D', 'X', 'P', 'A', 'C', 'K', '2'};
+const char PACK_MAGIC[8] = {'G', 'D', 'X', 'P', 'A', 'C', 'K', '3'};
+// 64-bit FNV-1a over the 8-byte words of the payload (records + buffers; everything behind the extras block, whose length is a
+// multiple of 8): the image's integrity check.  It lives in PackHdr::pad (low half) and the fourth extras word (high half).
+static uint64_t pack_hash(const char* p, const char* end) {
+    uint64_t h = 0xcbf29ce484222325ull;
+    for (; p + 8 <= end; p += 8) {
+        uint64_t w;
+        memcpy(&w, p, 8);
+        h = (h ^ w) * 0x100000001b3ull;
+    }
+    for (; p < end; ++p) h = (h ^ (unsigned char)*p) * 0x100000001b3ull;
+    return h;
+}
 struct PackBuf { void** ptr; size_t bytes; PackRec rec; };
 }  // namespace
 
@@ -464,9 +475,11 @@ extern "C" int gdx_export_packed(gdx_handle_t h, void* host, int64_t bytes, void
     PackHdr hd{};
     memcpy(hd.magic, PACK_MAGIC, 8);
     hd.cfg = h->cfg; hd.nrec = (int32_t)bufs.size();
-    memcpy(p, &hd, sizeof(hd)); p += sizeof(hd);
-    const int32_t extra[4] = {h->pe_rows, h->rope_rows, h->cfg.compute_dtype, 0};
-    memcpy(p, extra, sizeof(extra)); p += sizeof(extra);
+    char* const hd_at = p; p += sizeof(hd);
+    int32_t extra[4] = {h->pe_rows, h->rope_rows, h->cfg.compute_dtype, 0};
+    char* const extra_at = p; p += sizeof(extra);
+    char* const payload = p;
+    memset(payload, 0, (size_t)(bytes - (payload - (char*)host)));  // the 16-byte alignment gaps are part of the hashed payload
     for (const PackBuf& b : bufs) {
         memcpy(p, &b.rec, sizeof(PackRec)); p += sizeof(PackRec);
         if (b.bytes) {
@@ -476,6 +489,11 @@ extern "C" int gdx_export_packed(gdx_handle_t h, void* host, int64_t bytes, void
         p += (b.bytes + 15) / 16 * 16;
     }
     HIPCHK(hipStreamSynchronize(s));
+    const uint64_t hash = pack_hash(payload, (char*)host + bytes);
+    hd.pad = (int32_t)(uint32_t)hash;
+    extra[3] = (int32_t)(uint32_t)(hash >> 32);
+    memcpy(hd_at, &hd, sizeof(hd));
+    memcpy(extra_at, extra, sizeof(extra));
     return 0;
 }
 
@@ -490,6 +508,7 @@ extern "C" int gdx_import_packed(gdx_handle_t h, const void* host, int64_t bytes
     if (memcmp(&hd.cfg, &h->cfg, sizeof(gdx_config_t))) return fail("gdx_import_packed: image was built for another configuration");
     int32_t extra[4];
     memcpy(extra, p, sizeof(extra)); p += sizeof(extra);
+    const uint64_t stored = (uint64_t)(uint32_t)hd.pad | ((uint64_t)(uint32_t)extra[3] << 32);
     if (extra[2] != h->cfg.compute_dtype) return fail("gdx_import_packed: image was built for another compute dtype");
     const int rope_need = h->cfg.arch == GDX_ARCH_MDM ? 1 : 0;
     if (extra[0] <= 0 || extra[0] > (1 << 20) || extra[1] < rope_need || extra[1] > (1 << 20))
@@ -512,6 +531,7 @@ extern "C" int gdx_import_packed(gdx_handle_t h, const void* host, int64_t bytes
         if (q > end) why = "gdx_import_packed: truncated image";
     }
     if (!why && q != end) why = "gdx_import_packed: trailing bytes";
+    if (!why && pack_hash(p, end) != stored) why = "gdx_import_packed: payload checksum mismatch (corrupted image)";
     if (why) {
         h->pe_rows = old_pe; h->rope_rows = old_rope;
         return fail(why);
@@ -520,6 +540,12 @@ extern "C" int gdx_import_packed(gdx_handle_t h, const void* host, int64_t bytes
     if (h->pe_rows != old_pe) h->pe = nullptr;
     if (h->rope_rows != old_rope) { h->rope_cos = nullptr; h->rope_sin = nullptr; }
     hipStream_t s = (hipStream_t)stream;
+    // from here on the handle's weights are being overwritten: it is "not ready" until the last byte has arrived (a failed
+    // allocation or copy must not leave a half-uploaded model that gdx_weights_ready accepts)
+    h->have.clear();
+    h->cond_set = false;
+    h->c2t_valid = false;
+    h->tables_valid = false;
     for (PackBuf& b : bufs) {
         p += sizeof(PackRec);
         if (b.bytes) {
@@ -692,9 +718,13 @@ extern "C" int gdx_set_condition(gdx_handle_t h, const float* seed, const float*
 }
 
 static int gemm(int am, int bm, int om, int ep, const GemmParams& p, hipStream_t s) {
-    static const bool force_v1 = getenv("GDX_GEMM_V1") != nullptr;   // A/B switch for measurements
     hipError_t e;
-    if (!force_v1 && am == A_ROWS && bm == B_WEIGHT) {
+    // Operands beyond the 2 GiB range of a buffer descriptor: the persistent kernel cannot address them and the 128 x 128 kernel
+    // of gemm.hip would silently produce other bits for the same rows (another summation order).  Refuse instead: the caller
+    // splits the batch (bench.py's config 4 runs sub-batches of 256 for this reason).
+    if ((long)(p.M + ROW_PAD) * p.lda * 4 >= (1L << 31) || (long)(p.M + ROW_PAD) * p.ldc * 4 >= (1L << 31))
+        return fail("gemm: an operand exceeds the 2 GiB buffer-descriptor range; run the batch in smaller pieces");
+    if (am == A_ROWS && bm == B_WEIGHT) {
         // persistent kernel: residual / per-sample-vector terms are selected by the pointers, not by the mode
         GemmParams q = p;
         int ep2 = ep;
@@ -707,6 +737,7 @@ static int gemm(int am, int bm, int om, int ep, const GemmParams& p, hipStream_t
             if (e != hipErrorNotSupported) return fail(std::string("launch_gemm2: ") + hipGetErrorString(e));
         }
     }
+    // shapes the persistent kernel does not take (N not a multiple of 64, K not a multiple of 32, unaligned rows)
     e = launch_gemm(am, bm, om, ep, p, s);
     if (e != hipSuccess) return fail(std::string("launch_gemm: ") + hipGetErrorString(e));
     return 0;
@@ -758,19 +789,14 @@ static int forward_core(gdx_model* h, const float* x, const float* temb, int tst
         const Layer& ly = h->layers[l];
         p = GemmParams{h->xa, d, ly.qkv.w, ly.qkv.kpad, ly.qkv.bias, nullptr, 0, nullptr, 0, h->qkv, 3 * d, N, 3 * d, d, T, B};
         if (gemm(A_ROWS, B_WEIGHT, OUT_ROWS, EPI_BIAS, p, s)) return -1;
-        static const bool attn_v1 = getenv("GDX_ATTN_V1") != nullptr;   // A/B switches for measurements
-        static const bool attn_v2 = getenv("GDX_ATTN_V2") != nullptr;
-        if (!attn_v1 && !attn_v2 && attention3_supported(S, h->H, d))
+        if (attention3_supported(S, h->H, d))
             HIPCHK(launch_attention3(h->qkv, h->ctx, Beff, S, h->H, d, s));
-        else if (!attn_v1 && attention2_supported(S, h->H, d))
-            HIPCHK(launch_attention2(h->qkv, h->ctx, Beff, S, h->H, d, s));
-        else
+        else                                              // other head dims / more than 256 tokens: the general 32 x 32-block kernel
             HIPCHK(launch_attention(h->qkv, h->ctx, Beff, S, h->H, d, s));
         // x = LN1(x + out_proj(ctx)): the residual add rides in the GEMM epilogue (prefetched one tile ahead, gemm2.hip)
-        static const bool res_in_ln = getenv("GDX_RES_IN_LN") != nullptr;   // A/B switch: residual add in LayerNorm
-        p = GemmParams{h->ctx, d, ly.out.w, ly.out.kpad, ly.out.bias, res_in_ln ? nullptr : h->xa, d, nullptr, 0, h->tmp, d, N, d, d, T, B};
-        if (gemm(A_ROWS, B_WEIGHT, OUT_ROWS, res_in_ln ? EPI_BIAS : EPI_RES, p, s)) return -1;
-        HIPCHK(launch_layernorm(h->tmp, res_in_ln ? h->xa : nullptr, ly.g1, ly.b1, h->xb, nullptr, N, d, 0, s));
+        p = GemmParams{h->ctx, d, ly.out.w, ly.out.kpad, ly.out.bias, h->xa, d, nullptr, 0, h->tmp, d, N, d, d, T, B};
+        if (gemm(A_ROWS, B_WEIGHT, OUT_ROWS, EPI_RES, p, s)) return -1;
+        HIPCHK(launch_layernorm(h->tmp, nullptr, ly.g1, ly.b1, h->xb, nullptr, N, d, 0, s));
         p = GemmParams{h->xb, d, ly.ff1.w, ly.ff1.kpad, ly.ff1.bias, nullptr, 0, nullptr, 0, h->ffb, h->ff, N, h->ff, d, T, B};
         const bool stamp = h->prof && h->prof_used + 2 <= h->prof_ev.size();
         if (stamp) HIPCHK(hipEventRecord(h->prof_ev[h->prof_used], s));
@@ -779,10 +805,10 @@ static int forward_core(gdx_model* h, const float* x, const float* temb, int tst
             HIPCHK(hipEventRecord(h->prof_ev[h->prof_used + 1], s));
             h->prof_used += 2;
         }
-        p = GemmParams{h->ffb, h->ff, ly.ff2.w, ly.ff2.kpad, ly.ff2.bias, res_in_ln ? nullptr : h->xb, d, nullptr, 0, h->tmp, d, N, d, h->ff, T, B};
-        if (gemm(A_ROWS, B_WEIGHT, OUT_ROWS, res_in_ln ? EPI_BIAS : EPI_RES, p, s)) return -1;
+        p = GemmParams{h->ffb, h->ff, ly.ff2.w, ly.ff2.kpad, ly.ff2.bias, h->xb, d, nullptr, 0, h->tmp, d, N, d, h->ff, T, B};
+        if (gemm(A_ROWS, B_WEIGHT, OUT_ROWS, EPI_RES, p, s)) return -1;
         const bool last = l + 1 == h->L;
-        const float* res2 = res_in_ln ? h->xb : nullptr;
+        const float* res2 = nullptr;
         // the last layer's output is only needed without token 0 (model/mdm.py:219): write it compacted [Beff*T, d]
         if (!last || h->keep_taps) HIPCHK(launch_layernorm(h->tmp, res2, ly.g2, ly.b2, h->xa, nullptr, N, d, 0, s));
         if (last) HIPCHK(launch_layernorm(h->tmp, res2, ly.g2, ly.b2, h->xc, nullptr, N, d, S, s));
@@ -1019,8 +1045,7 @@ extern "C" int gdx_sample_loop(gdx_handle_t h, const gdx_loop_args_t* a, void* s
     // (no inpainting, no dumps; the tape is read in place), the state stays in the input GEMM's operand layout for the whole
     // call -- one transpose in front, none per step (2 launches and ~40 MB per step less), the last update also writes the
     // sample in the reference layout.  Bit-identical to the general path (tests: fused Philox loop == step-wise Philox loop).
-    static const bool no_tm = getenv("GDX_LOOP_NO_TM") != nullptr;           // A/B switch
-    if (!no_tm && !((uintptr_t)a->noise_tape & 15) && !a->inpaint_mask && !a->n_dump && !h->graph_replay && !h->keep_taps && h->T % 4 == 0) {
+    if (!((uintptr_t)a->noise_tape & 15) && !a->inpaint_mask && !a->n_dump && !h->graph_replay && !h->keep_taps && h->T % 4 == 0) {
         const int Beff = a->mode == GDX_CFG ? 2 * B : B;
         // half modes: the fp32 state keeps the half operand's row stride, and the update kernel also writes that operand
         const int ldx = h->f16 ? h->in_x.kpad16 : h->in_x.kpad;
@@ -1373,7 +1398,8 @@ extern "C" int gdx_attention_f32(const float* qkv, float* ctx, int32_t B, int32_
     if (!qkv || !ctx || B <= 0 || S <= 0 || H <= 0 || d <= 0 || d % H) return fail("gdx_attention_f32: bad argument");
     const int hd = d / H;
     if (hd != 32 && hd != 64 && hd != 128 && hd != 256) return fail("gdx_attention_f32: head_dim must be 32, 64, 128 or 256");
-    if ((version == 2 && !attention2_supported(S, H, d)) || ((version == 3 || version == 5) && !attention3_supported(S, H, d)))
+    if (version == 2) return fail("gdx_attention_f32: kernel version 2 (attention2.hip) was removed in round 3");
+    if ((version == 3 || version == 5) && !attention3_supported(S, H, d))
         return fail("gdx_attention_f32: shape not supported by the requested kernel");
     hipStream_t s = (hipStream_t)stream;
     const size_t rows = (size_t)B * S, prow = rows + GDX_ROW_PAD;
@@ -1388,7 +1414,6 @@ extern "C" int gdx_attention_f32(const float* qkv, float* ctx, int32_t B, int32_
         hipError_t e;
         if (version == 5) e = launch_attention3(q, c, B, S, H, d, s, (B * H + 2) / 3);   // persistent, ~3 items per workgroup
         else if (version == 3 || (version == 0 && attention3_supported(S, H, d))) e = launch_attention3(q, c, B, S, H, d, s);
-        else if (version == 2 || (version == 0 && attention2_supported(S, H, d))) e = launch_attention2(q, c, B, S, H, d, s);
         else e = launch_attention(q, c, B, S, H, d, s);
         if (e != hipSuccess) rc = fail(std::string("gdx_attention_f32: ") + hipGetErrorString(e));
     }
@@ -1421,7 +1446,6 @@ extern "C" int gdx_bench_gemm_f16(int32_t M, int32_t N, int32_t K, int32_t gelu,
         rc = fail("gdx_bench_gemm_f16: operand fill failed");
     GemmHParams p{a16, K, w16, K, (int)((size_t)M * K * 2), (int)((size_t)npad * K * 2), bias, nullptr, 0, nullptr, 0,
                   nullptr, 0, c16, N, M, N, K, 1, 0, gelu};
-    if (getenv("GDX_BENCH_GEMM_R") && N <= K) { p.R = Af; p.ldr = N; }   // diagnostic: an fp32 per-row term streamed by the epilogue
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (!rc && (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess)) rc = fail("hipEventCreate failed");
     for (int i = 0; !rc && i < 3; ++i)
@@ -1489,7 +1513,6 @@ extern "C" int gdx_bench_attention(int32_t B, int32_t S, int32_t H, int32_t d, i
     auto run = [&]() -> hipError_t {
         if (version == 3) return HFN(g_test_bf16, launch_attentionh, qkv16, ctx16, B, S, H, d, (long)rows, s);
         if (version == 4 && attention3_supported(S, H, d)) return launch_attention3(qkv, ctx, B, S, H, d, s);
-        if (version == 2 && attention2_supported(S, H, d)) return launch_attention2(qkv, ctx, B, S, H, d, s);
         return launch_attention(qkv, ctx, B, S, H, d, s);
     };
     hipEvent_t e0, e1;

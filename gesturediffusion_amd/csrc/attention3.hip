@@ -1,6 +1,7 @@
 // Encoder self-attention core, third version: eight MFMA waves, one pass, balanced SIMDs.
 //
-// attention2.hip runs one MFMA wave per SIMD with two resident query blocks and makes two passes over the K/V tiles.
+// Its predecessor (attention2.hip, removed in round 3; DESIGN.md section 4 keeps the measurements) ran one MFMA wave per SIMD
+// with two resident query blocks and made two passes over the K/V tiles.
 // For the 197-token sequences of the BASELINE configs (13 query blocks of 16) that leaves two structural losses,
 // both visible in the PMC matrix-pipe utilisation (0.57):
 //   * 13 blocks on 4 SIMDs is 4,3,3,3: SIMD 0 works a quarter longer than the others, and the per-tile barrier makes
@@ -18,7 +19,7 @@
 //     64-key tiles (4 key blocks), double-buffered (2 x 66 KiB for head_dim 128): 4 barriers per launch instead of 14;
 //   * no loader waves: every wave issues its 8-9 LDS-DMA pieces of the next tile at the start of a tile (the other
 //     wave of the SIMD keeps the matrix pipe busy meanwhile).
-// The MFMA / softmax / fragment layout is attention2.hip's (S^T = K Q^T, O^T += V^T P^T, deferred max, register rings).
+// MFMA / softmax / fragment layout: S^T = K Q^T, O^T += V^T P^T, deferred max, register rings (as in attentionh.hip).
 #include "gdx_internal.h"
 
 #include <cstdlib>
@@ -164,7 +165,7 @@ __global__ __launch_bounds__(512, 1) void attention3_kernel(const float* __restr
                     s[qi] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[c], qf[qi][kk][c], s[qi], 0, 0, 0);
             __builtin_amdgcn_sched_group_barrier(0x008, 4 * NQ, 0);
         }
-        // online softmax per query (lane column l15; keys 4lq+e in this lane), deferred max as in attention2.hip
+        // online softmax per query (lane column l15; keys 4lq+e in this lane), deferred max
         const bool tail = key0 + 16 > S;                              // wave-uniform: only the last key block masks
 #pragma unroll
         for (int qi = 0; qi < NQ; ++qi) {
@@ -430,14 +431,13 @@ bool attention3_supported(int S, int H, int d) {
 
 // grid = 0: one workgroup per (sample, head), or -- with at least two items per workgroup slot of that launch -- the
 // persistent variant on one workgroup per CU; grid > 0 forces the persistent variant on that many workgroups (tests,
-// A/B); env GDX_ATTN3_PERSIST=0 / 1 overrides the choice.
+// A/B).
 hipError_t launch_attention3(const float* qkv, float* ctx, int B, int S, int H, int d, hipStream_t s, int grid) {
     const int hd = d / H, nitems = B * H;
     if (hd != 128 && hd != 64) return hipErrorInvalidValue;
-    static const char* force = getenv("GDX_ATTN3_PERSIST");
     const int cus = gemm2_num_cus();
     // head_dim 64: two item-resident workgroups fit on a CU side by side (110 VGPRs, 64 KiB), one persistent one (141)
-    bool persist = grid > 0 || (force ? force[0] == '1' : nitems >= 2 * cus * (hd == 64 ? 2 : 1));
+    bool persist = grid > 0 || nitems >= 2 * cus * (hd == 64 ? 2 : 1);
     if (grid <= 0) grid = cus;
     if (grid >= nitems) persist = false;                              // nothing to walk
     if (!persist) return hd == 128 ? launch_a3<128, false>(qkv, ctx, B, S, H, d, nitems, s) : launch_a3<64, false>(qkv, ctx, B, S, H, d, nitems, s);

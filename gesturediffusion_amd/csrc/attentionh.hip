@@ -2,9 +2,12 @@
 // v_mfma_f32_16x16x32_f16, fp32 scores / softmax / accumulators, fp16 Q, K, V, P operands and output.
 //   qkv [B*S][3d] halves (q | k | v, heads contiguous inside each)  ->  ctx [B*S][d] halves.
 //
-// Structure (same wave roles as attention2.hip): one 512-thread workgroup per (sample, head, query chunk); waves 0-3
-// each keep QB = 2 query blocks of 16 resident (Q fragments + O^T accumulators in registers) and walk all K/V tiles
-// of 32 keys once; waves 4-7 stage the tiles with LDS-DMA into a 4-stage ring (counted vmcnt, raw barriers).
+// Structure: one 512-thread workgroup per (sample, head, query chunk) -- or, persistent, per CU walking such items; all eight
+// waves compute, each keeps one or two query blocks of 16 resident (Q fragments + O^T accumulators in registers), walks all
+// K/V tiles of 32 keys once and issues 1/8 of every tile's LDS-DMA into a 4-stage ring (counted vmcnt, raw barriers).
+// (The first kernel of this file, 4 compute + 4 loader waves, was removed in round 3; restructures that were measured and
+// not kept -- one wave per SIMD with 512 registers, SIMD partners rotated by half a tile -- are recorded in
+// profiles/r03b_fp16_attention_experiments.txt.)
 //   * S^T = K Q^T (K fragment = A operand, ds_read_b128 of 8 consecutive head-dim halves of one key): the query sits
 //     on the accumulator's lane axis, so max / sum / rescale are per-lane scalars and the 8 probabilities a lane
 //     holds for a 32-key tile (2 blocks x 4 registers), rounded to fp16, ARE the B operand of the next product --
@@ -52,228 +55,6 @@ __device__ __forceinline__ int ah_records(long remaining) { return remaining > 0
 __device__ __forceinline__ f16x4 lds_read_tr(const char* p) {
     const fp16x4_t v = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4_t*)(p));
     return __builtin_bit_cast(f16x4, v);
-}
-
-template <int HD, int QB>
-__global__ __launch_bounds__(512, 1) void attentionh_kernel(const _Float16* __restrict__ qkv, _Float16* __restrict__ ctx,
-                                                            int S, int H, int d, int nchunk, float c_log2,
-                                                            long qkv_bytes) {
-#if defined(__HIP_DEVICE_COMPILE__)   // buffer-resource builtins are device-only (the host pass needs just the stub)
-    constexpr int ROWB = HD * 2;                 // bytes per K / V row in LDS
-    constexpr int CPR = ROWB / 16;               // 16-byte chunks per row
-    constexpr int T_BYTES = 32 * ROWB;           // one 32-key tile of K (or V)
-    constexpr int STAGE_BYTES = 2 * T_BYTES;
-    constexpr int T_P = T_BYTES / 1024, P = 2 * T_P, PW = (P + 3) / 4;
-    constexpr int NST = 4;
-    constexpr int NKS = HD / 32;                 // MFMA k-steps along head_dim (QK^T)
-    constexpr int NNB = HD / 16;                 // 16-wide head-dim blocks (PV)
-    constexpr float RESCALE_THR = 8.0f;          // log2 units
-    static_assert(HD == 32 || HD == 64 || HD == 128 || HD == 256, "head_dim");
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid) >> 6;
-    const int l15 = lane & 15, lq = lane >> 4;
-    const int ci = blockIdx.x % nchunk;
-    const int h = (blockIdx.x / nchunk) % H, b = blockIdx.x / (nchunk * H);
-    const long ld = 3L * d;
-    const long base_off = (long)b * S * ld + h * HD;          // halves
-    const _Float16* base = qkv + base_off;
-    const int nqb = (S + 15) / 16;
-    const int qb_lo = (int)((long)ci * nqb / nchunk), qb_hi = (int)((long)(ci + 1) * nqb / nchunk);
-    const int ntiles = (S + 31) / 32;
-
-    auto fswz = [](int row) { return HD == 32 ? ((row >> 2) & 1) << 1 : HD == 64 ? ((row >> 1) & 3) << 1 : (row & 7) << 1; };
-
-    if (wave >= 4) {
-        // ================================================================== loader waves: LDS-DMA of K/V tiles
-        const long kb_off = (base_off + d) * 2, vb_off = (base_off + 2 * d) * 2;
-        const auto rsrcK = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(base + d), (short)0,
-                                                             ah_records(qkv_bytes - kb_off), 0x00020000);
-        const auto rsrcV = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(base + 2 * d), (short)0,
-                                                             ah_records(qkv_bytes - vb_off), 0x00020000);
-        int voff[PW];
-#pragma unroll
-        for (int i = 0; i < PW; ++i) {
-            int piece = (wave & 3) + 4 * i;
-            piece = piece < P ? piece : P - 1;
-            const int pl = piece < T_P ? piece : piece - T_P;
-            const int row = pl * (1024 / ROWB) + lane / CPR;
-            const int chunk = (lane % CPR) ^ fswz(row);
-            voff[i] = (int)(row * ld * 2) + chunk * 16;
-        }
-        int kt = 0;
-        auto issue = [&](int stage) {
-            const int so = (int)((long)kt * 32 * ld * 2);
-            char* sb = smem + stage * STAGE_BYTES;
-#pragma unroll
-            for (int i = 0; i < PW; ++i) {
-                int piece = (wave & 3) + 4 * i;
-                piece = piece < P ? piece : P - 1;
-                if (piece < T_P)
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcK, (lds_ptr_t)(sb + piece * 1024), 16, voff[i], so, 0, 0);
-                else
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcV, (lds_ptr_t)(sb + T_BYTES + (piece - T_P) * 1024), 16,
-                                                             voff[i], so, 0, 0);
-            }
-            asm volatile("" ::: "memory");
-            if (++kt == ntiles) kt = ntiles - 1;                      // past the end: harmless re-reads of the last tile
-        };
-#pragma unroll
-        for (int s = 0; s < NST - 1; ++s) issue(s);
-        ah_wait_vm<(NST - 2) * PW>();                                 // tile 0 landed
-        asm volatile("s_barrier" ::: "memory");
-        int wst = NST - 1;
-        for (int g = 0; g < ntiles; ++g) {
-            issue(wst);                                               // tile g+NST-1 -> the stage freed by the last barrier
-            wst = wst == NST - 1 ? 0 : wst + 1;
-            ah_wait_vm<(NST - 2) * PW>();                             // tile g+1 landed
-            asm volatile("s_barrier" ::: "memory");
-        }
-        ah_wait_vm<0>();
-        return;
-    }
-
-    // ====================================================================== consumer waves
-    const int nblk = qb_hi - qb_lo;                                   // <= 4 * QB
-    const int mine = wave < nblk ? min((nblk - wave + 3) / 4, QB) : 0;  // blocks qb_lo + wave + 4*qi
-
-    f16x8 qf[QB][NKS];
-    f32x4 o[QB][NNB];
-    float m_run[QB], l_run[QB];
-#pragma unroll
-    for (int qi = 0; qi < QB; ++qi) {
-        int q = 16 * (qb_lo + wave + 4 * qi) + l15;
-        q = q < S ? q : S - 1;
-        const _Float16* qp = base + (long)q * ld + 8 * lq;
-#pragma unroll
-        for (int ks = 0; ks < NKS; ++ks) {
-            f16x8 v = f16x8{0, 0, 0, 0, 0, 0, 0, 0};
-            if (qi < mine) v = *reinterpret_cast<const f16x8*>(qp + 32 * ks);
-            qf[qi][ks] = v;
-        }
-#pragma unroll
-        for (int nb = 0; nb < NNB; ++nb) o[qi][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
-        m_run[qi] = -INFINITY;
-        l_run[qi] = 0.0f;
-    }
-    const int kbase = l15 * ROWB + ((lq ^ fswz(l15)) << 4);
-    const int vrow = 4 * lq + (l15 >> 2);
-    const int vbase = T_BYTES + vrow * ROWB + ((fswz(vrow) >> 1) << 5) + (l15 & 3) * 8;
-
-    asm volatile("s_barrier" ::: "memory");                           // tile 0 landed
-    int stage = 0;
-    auto run_tiles = [&](auto nq_tag) {
-        constexpr int NQ = decltype(nq_tag)::value;
-        for (int kt = 0; kt < ntiles; ++kt) {
-            const char* St = smem + stage * STAGE_BYTES;
-            if (NQ > 0) {
-                // ---- S^T[key][query]: two 16-key blocks x NQ query blocks; K fragments read once per (kb, ks), through
-                //      a register ring that runs PD reads ahead of the MFMAs (a read issued right in front of its
-                //      MFMAs exposed the ~120-cycle LDS latency 16 times per tile: 4 700 cycles per tile instead of ~1 800)
-                f32x4 s[QB][2];
-#pragma unroll
-                for (int qi = 0; qi < QB; ++qi) s[qi][0] = s[qi][1] = f32x4{0.f, 0.f, 0.f, 0.f};
-                constexpr int NR = 2 * NKS, PD = NR < 4 ? NR - 1 : 3;
-                auto kread = [&](int r) {
-                    return *reinterpret_cast<const f16x8*>(St + ((kbase + (r / NKS) * 16 * ROWB) ^ ((r % NKS) << 6)));
-                };
-                f16x8 kring[PD + 1];
-#pragma unroll
-                for (int r = 0; r < PD; ++r) kring[r] = kread(r);
-#pragma unroll
-                for (int r = 0; r < NR; ++r) {
-                    if (r + PD < NR) kring[(r + PD) % (PD + 1)] = kread(r + PD);
-#pragma unroll
-                    for (int qi = 0; qi < NQ; ++qi)
-                        s[qi][r / NKS] = GDX_MFMA16(kring[r % (PD + 1)], qf[qi][r % NKS], s[qi][r / NKS], 0, 0, 0);
-                }
-                // the first V^T fragments are requested before the softmax so that their latency hides behind it
-                constexpr int VD = NNB < 4 ? NNB - 1 : 3;
-                auto vread = [&](int nb, int half) { return lds_read_tr(St + ((vbase + half * 16 * ROWB) ^ (nb << 5))); };
-                f16x4 vring[VD + 1][2];
-#pragma unroll
-                for (int nb = 0; nb < VD; ++nb) {
-                    vring[nb][0] = vread(nb, 0);
-                    vring[nb][1] = vread(nb, 1);
-                }
-                // ---- online softmax per query (lane column l15; this lane's keys: 32kt + 16kb + 4lq + e)
-                f16x8 pf[QB];
-                const bool tail = kt * 32 + 32 > S;                   // block-uniform
-#pragma unroll
-                for (int qi = 0; qi < NQ; ++qi) {
-                    float v[8];
-#pragma unroll
-                    for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[kb * 4 + e] = s[qi][kb][e];
-                    if (tail) {
-#pragma unroll
-                        for (int j = 0; j < 8; ++j)
-                            if (kt * 32 + (j >> 2) * 16 + 4 * lq + (j & 3) >= S) v[j] = -INFINITY;
-                    }
-                    float mx = fmaxf(fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3])), fmaxf(fmaxf(v[4], v[5]), fmaxf(v[6], v[7]))) * c_log2;
-                    if (__any(mx > m_run[qi] + RESCALE_THR)) {        // wave-uniform, rare after the first tile
-                        mx = fmaxf(mx, __shfl_xor(mx, 16));
-                        mx = fmaxf(mx, __shfl_xor(mx, 32));
-                        const float m_new = fmaxf(m_run[qi], mx);
-                        const float alpha = __builtin_amdgcn_exp2f(m_run[qi] - m_new);
-                        l_run[qi] *= alpha;
-#pragma unroll
-                        for (int nb = 0; nb < NNB; ++nb) o[qi][nb] *= alpha;
-                        m_run[qi] = m_new;
-                    }
-                    float psum = 0.0f;
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        v[j] = __builtin_amdgcn_exp2f(fmaf(v[j], c_log2, -m_run[qi]));
-                        psum += v[j];
-                    }
-                    l_run[qi] += psum;
-                    pf[qi] = f16x8{(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3],
-                                   (half_t)v[4], (half_t)v[5], (half_t)v[6], (half_t)v[7]};
-                }
-                // ---- O^T += V^T P^T: transposed reads of V (keys 4lq.. of block 0, then of block 1) feed all query blocks
-#pragma unroll
-                for (int nb = 0; nb < NNB; ++nb) {
-                    if (nb + VD < NNB) {
-                        vring[(nb + VD) % (VD + 1)][0] = vread(nb + VD, 0);
-                        vring[(nb + VD) % (VD + 1)][1] = vread(nb + VD, 1);
-                    }
-                    const f16x4 v0 = vring[nb % (VD + 1)][0], v1 = vring[nb % (VD + 1)][1];
-                    const f16x8 vf = f16x8{v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-#pragma unroll
-                    for (int qi = 0; qi < NQ; ++qi)
-                        o[qi][nb] = GDX_MFMA16(vf, pf[qi], o[qi][nb], 0, 0, 0);
-                }
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // tile consumed; the loaders waited for the next one
-            stage = stage == NST - 1 ? 0 : stage + 1;
-        }
-    };
-    if (mine == 2) run_tiles(std::integral_constant<int, 2>{});
-    else if (mine == 1) run_tiles(std::integral_constant<int, 1>{});
-    else run_tiles(std::integral_constant<int, 0>{});
-
-    // ---- normalise and store: lane (query l15, group lq) holds hd = 16nb + 4lq + e
-#pragma unroll
-    for (int qi = 0; qi < QB; ++qi) {
-        if (qi >= mine) continue;
-        float l_tot = l_run[qi];
-        l_tot += __shfl_xor(l_tot, 16);
-        l_tot += __shfl_xor(l_tot, 32);
-        const float inv = 1.0f / l_tot;
-        const int q = 16 * (qb_lo + wave + 4 * qi) + l15;
-        if (q < S) {
-            _Float16* op = ctx + ((long)b * S + q) * d + h * HD + 4 * lq;
-#pragma unroll
-            for (int nb = 0; nb < NNB; ++nb) {
-                const f32x4 r = o[qi][nb] * inv;
-                *reinterpret_cast<f16x4*>(op + 16 * nb) = f16x4{(half_t)r[0], (half_t)r[1], (half_t)r[2], (half_t)r[3]};
-            }
-        }
-    }
-#endif
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -960,24 +741,6 @@ static hipError_t launch_ah8(const _Float16* qkv, _Float16* ctx, int B, int S, i
     return hipGetLastError();
 }
 
-template <int HD, int QB>
-static hipError_t launch_ah(const _Float16* qkv, _Float16* ctx, int B, int S, int H, int d, long qkv_bytes, hipStream_t s) {
-    const size_t lds = (size_t)4 * 2 * 32 * HD * 2;
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attentionh_kernel<HD, QB>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        attr_done = true;
-    }
-    const int nqb = (S + 15) / 16;
-    const int nchunk = (nqb + 4 * QB - 1) / (4 * QB);
-    const float c_log2 = 1.4426950408889634f / sqrtf((float)HD);
-    hipLaunchKernelGGL((attentionh_kernel<HD, QB>), dim3(B * H * nchunk), dim3(512), lds, s, qkv, ctx, S, H, d, nchunk,
-                       c_log2, qkv_bytes);
-    return hipGetLastError();
-}
-
 bool attentionh_supported(int S, int H, int d) {
     const int hd = d / H;
     return (hd == 32 || hd == 64 || hd == 128 || hd == 256) && d % 8 == 0 && S >= 1;
@@ -987,37 +750,27 @@ bool attentionh_supported(int S, int H, int d) {
 hipError_t launch_attentionh(const _Float16* qkv, _Float16* ctx, int B, int S, int H, int d, long qkv_rows, hipStream_t s) {
     const int hd = d / H;
     const long bytes = qkv_rows * 3L * d * 2;
-    // measured (tools/attnh_one.py, us): B=128 S=521 hd=256: 4+4 waves 318, 8 waves x 1 block 373, 8 waves x 2 blocks 292;
-    // B=16 (config 5's per-GPU share): 49.5 / 58.9 / 37.4;  B=64 S=197 hd=128: 23.3 / 19.9 / 18.7.  The 8 x 2 kernel needs
-    // enough workgroups to fill the chip (it makes half as many), so small problems keep the older choices.
-    static const char* force = getenv("GDX_ATTNH_WAVES");            // A/B switch: "4", "8", "q" (8 waves x 2 blocks) or "p" (persistent)
+    // measured (tools/attnh_one.py, us): B=128 S=521 hd=256: 8 waves x 1 block 373, 8 waves x 2 blocks 292, persistent 273-285;
+    // B=16 (config 5's per-GPU share): 58.9 / 37.4;  B=64 S=197 hd=128: 19.9 / 18.7.  The 8 x 2 kernels need enough
+    // workgroups to fill the chip (they make half as many), so small problems keep one block per wave.
     const int nqb = (S + 15) / 16;
     const long nitems = (long)B * H * ((nqb + 15) / 16);
     const int num_cus = gemm2_num_cus();
-    // persistent form once every CU has at least two items to chain (measured: tools/ab_attnp.sh, profiles/r02h_*)
-    const bool usep = force ? force[0] == 'p' : (hd >= 64 && nitems >= 2L * num_cus);
-    if (usep) {
+    // persistent form once every CU has at least two items to chain (profiles/r02h_*)
+    if (hd >= 64 && nitems >= 2L * num_cus) {
         if (hd == 256) return launch_ah8p<256>(qkv, ctx, B, S, H, d, bytes, num_cus, s);
         if (hd == 128) return launch_ah8p<128>(qkv, ctx, B, S, H, d, bytes, num_cus, s);
-        if (hd == 64) return launch_ah8p<64>(qkv, ctx, B, S, H, d, bytes, num_cus, s);
+        return launch_ah8p<64>(qkv, ctx, B, S, H, d, bytes, num_cus, s);
     }
-    const bool useq = force ? force[0] == 'q' : (hd >= 64 && nitems >= 128);
-    if (useq) {
+    if (hd >= 64 && nitems >= 128) {
         if (hd == 256) return launch_ah8q<256>(qkv, ctx, B, S, H, d, bytes, s);
         if (hd == 128) return launch_ah8q<128>(qkv, ctx, B, S, H, d, bytes, s);
-        if (hd == 64) return launch_ah8q<64>(qkv, ctx, B, S, H, d, bytes, s);
+        return launch_ah8q<64>(qkv, ctx, B, S, H, d, bytes, s);
     }
-    const bool use8 = force ? force[0] == '8' : hd <= 128;
-    if (use8) {
-        if (hd == 256) return launch_ah8<256>(qkv, ctx, B, S, H, d, bytes, s);
-        if (hd == 128) return launch_ah8<128>(qkv, ctx, B, S, H, d, bytes, s);
-        if (hd == 64) return launch_ah8<64>(qkv, ctx, B, S, H, d, bytes, s);
-        if (hd == 32) return launch_ah8<32>(qkv, ctx, B, S, H, d, bytes, s);
-    }
-    if (hd == 256) return launch_ah<256, 2>(qkv, ctx, B, S, H, d, bytes, s);
-    if (hd == 128) return launch_ah<128, 2>(qkv, ctx, B, S, H, d, bytes, s);
-    if (hd == 64) return launch_ah<64, 2>(qkv, ctx, B, S, H, d, bytes, s);
-    if (hd == 32) return launch_ah<32, 2>(qkv, ctx, B, S, H, d, bytes, s);
+    if (hd == 256) return launch_ah8<256>(qkv, ctx, B, S, H, d, bytes, s);
+    if (hd == 128) return launch_ah8<128>(qkv, ctx, B, S, H, d, bytes, s);
+    if (hd == 64) return launch_ah8<64>(qkv, ctx, B, S, H, d, bytes, s);
+    if (hd == 32) return launch_ah8<32>(qkv, ctx, B, S, H, d, bytes, s);
     return hipErrorInvalidValue;
 }
 

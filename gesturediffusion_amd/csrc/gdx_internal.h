@@ -83,9 +83,6 @@ struct GemmHParams {
 // qkv [B*S][3d] (q | k | v, heads contiguous inside each), ctx [B*S][d]
 hipError_t launch_attention(const float* qkv, float* ctx, int B, int S, int H, int d, hipStream_t s);
 
-// 16-row-granular variant for head_dim 64/128 and <= 256 tokens (attention2.hip)
-bool attention2_supported(int S, int H, int d);
-hipError_t launch_attention2(const float* qkv, float* ctx, int B, int S, int H, int d, hipStream_t s);
 // eight-wave single-pass variant with the last query block shared out over four waves (attention3.hip); needs 64
 // readable rows past the last sample
 bool attention3_supported(int S, int H, int d);

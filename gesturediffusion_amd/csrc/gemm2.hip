@@ -466,9 +466,8 @@ hipError_t launch_gemm2(int omode, int epi, const GemmParams& p, hipStream_t s) 
     const int f_mb = g2_test_tile[0] ? g2_test_tile[0] : force_mb, f_nbw = g2_test_tile[0] ? g2_test_tile[1] : force_nbw,
               f_bk = g2_test_tile[0] ? g2_test_tile[2] : force_bk;     // gdx_linear_f32's tile argument wins over the environment
     double best = 1e30;
-    static const bool no_nst2 = getenv("GDX_GEMM_NO_NST2") != nullptr;     // A/B switch: without the two-stage 64-deep shapes
 #define X(mb, nbw, bk, nst)                                                                       \
-    if (g4_valid(mb, nbw, bk, nst, p) && !(nst == 2 && (no_nst2 || p.R))) {                            \
+    if (g4_valid(mb, nbw, bk, nst, p) && !(nst == 2 && p.R)) {                            \
         double c = g4_cost(mb, nbw, bk, p.M, p.N, p.K, num_cus);                                  \
         if (f_mb == mb && f_nbw == nbw && f_bk == bk) c = 0.0;                                    \
         if (c < best) { best = c; best_mb = mb; best_nbw = nbw; best_bk = bk; }                   \

@@ -459,252 +459,13 @@ __global__ __launch_bounds__(512, 1) void gemmh_kernel(const GemmHParams p, cons
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// 256 x 256 tile, eight MFMA waves (2 x 4, each 128 x 64 like the kernel above), no dedicated loader waves.
-// Measured on the 128 x 256 kernel (ablation builds, M = 66 688, N = 3 072, K = 1 024): MFMA alone 385 us,
-// LDS-DMA alone 518 us -- the L2 -> LDS path sustains ~23 B/clk/CU, and a 128 x 256 tile needs 48 B/clk/CU to keep
-// the fp16 MFMA busy.  A 256 x 256 tile halves the staged bytes per MFMA (32 KiB per 64 MFMAs per SIMD); it needs
-// 8 x 128 accumulator registers, i.e. all eight waves computing, so every wave also issues its 1/8 of the DMA
-// (4 pieces per K step, spread between its MFMAs) and the two waves of a SIMD cover each other's issue stalls and
-// fragment reads.  Counted vmcnt waits stay valid with the epilogue's stores in flight (the count includes them,
-// so the wait can only be longer than needed, never shorter).
-template <int NST>
-__global__ __launch_bounds__(512, 1) void gemmh8_kernel(const GemmHParams p, const int ntn, const int ntiles,
-                                                        unsigned long long* dbg) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    constexpr int MB = 8, NBW = 4, WM = 128, WN = 64, BM = 256, BN = 256;
-    constexpr int A_BYTES = BM * 64, W_BYTES = BN * 64, STAGE_BYTES = A_BYTES + W_BYTES;      // 32 KiB
-    constexpr int A_P = A_BYTES / 1024, P = STAGE_BYTES / 1024, PW = P / 8;                    // 4 pieces per wave
-    constexpr int SHW = ColMap<NBW>::QSH;
-    constexpr int VM_STEP = (NST - 3) * PW;
-    static_assert(NST >= 4 && P % 8 == 0, "ring depth");
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* const bias_lds = reinterpret_cast<float*>(smem + NST * STAGE_BYTES);
-
-    const int tid = threadIdx.x;
-    const int wave = __builtin_amdgcn_readfirstlane(tid) >> 6;
-    const int wr = wave >> 2, wc = wave & 3;
-    const int lane = tid & 63;
-    const int l15 = lane & 15, lq = lane >> 4;
-    const int G = gridDim.x;
-    int lid;
-    {
-        const int bid = blockIdx.x, q = G >> 3, r = G & 7, xcd = bid & 7, idx = bid >> 3;
-        lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    }
-    const int my_tiles = lid < ntiles ? (ntiles - lid + G - 1) / G : 0;
-    const int nk = p.K / 32;
-    const int total = my_tiles * nk;
-    if (total == 0) return;
-    for (int i = tid; i < p.N; i += 512) bias_lds[i] = p.bias ? p.bias[i] : 0.0f;
-
-    // ---- DMA set-up: this wave's 4 pieces of every slab (pieces wave, wave+8, ...: 2 of A, 2 of W)
-    const auto rsrcA = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(p.A), (short)0, p.a_bytes, 0x00020000);
-    const auto rsrcW = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(p.W), (short)0, p.w_bytes, 0x00020000);
-    int voff[PW];
-#pragma unroll
-    for (int i = 0; i < PW; ++i) {
-        const int piece = wave + 8 * i;
-        const bool isA = piece < A_P;
-        const int row = (isA ? piece : piece - A_P) * 16 + (lane >> 2);
-        const int g = (-(row >> (isA ? 2 : SHW))) & 3;
-        voff[i] = row * (isA ? p.lda : p.ldw) * 2 + (((lane & 3) ^ g) * 16);
-    }
-    // The DMA stream runs NST-1 slabs ahead of the MFMAs, so it crosses a tile boundary before they do.  Its tile
-    // base offsets advance by a select (no branch: the DMA issue must stay in the MFMA basic block to be interleaved);
-    // the base of the tile after next is computed once per tile, in the epilogue branch.
-    auto tile_base = [&](int ti, int& a_so, int& w_so) {
-        const int t = ti < my_tiles ? ti : my_tiles - 1;          // past the end: harmless re-reads
-        const int tile = lid + t * G;
-        a_so = (tile / ntn) * BM * p.lda * 2;
-        w_so = (tile % ntn) * BN * p.ldw * 2;
-    };
-    int ld_ks = 0, a_cur, w_cur, a_nxt, w_nxt;
-    tile_base(0, a_cur, w_cur);
-    tile_base(1, a_nxt, w_nxt);
-    auto issue = [&](int stage) {
-        const int a_so = a_cur + ld_ks * 64, w_so = w_cur + ld_ks * 64;
-        char* sb = smem + stage * STAGE_BYTES;
-#pragma unroll
-        for (int i = 0; i < PW; ++i) {
-            const int piece = wave + 8 * i;
-            if (piece < A_P)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcA, (lds_ptr_t)(sb + piece * 1024), 16, voff[i], a_so, 0, 0);
-            else
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcW, (lds_ptr_t)(sb + A_BYTES + (piece - A_P) * 1024), 16,
-                                                         voff[i], w_so, 0, 0);
-        }
-        ++ld_ks;
-        const bool wrap = ld_ks == nk;
-        ld_ks = wrap ? 0 : ld_ks;
-        a_cur = wrap ? a_nxt : a_cur;
-        w_cur = wrap ? w_nxt : w_cur;
-    };
-
-    f32x4 acc[MB][NBW];
-#pragma unroll
-    for (int i = 0; i < MB; ++i)
-#pragma unroll
-        for (int j = 0; j < NBW; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const int gq = (-(l15 >> 2)) & 3;
-    const int a_off = (wr * WM + l15) * 64 + ((lq ^ gq) * 16);
-    const int w_off = A_BYTES + (wc * WN + (l15 >> 2) * ColMap<NBW>::QS + (l15 & 3)) * 64 + ((lq ^ gq) * 16);
-    f16x8 fa0[MB], fw0[NBW], fa1[MB], fw1[NBW];
-    auto rd = [&](f16x8 (&fa)[MB], f16x8 (&fw)[NBW], int stage) {
-        const char* S = smem + stage * STAGE_BYTES;
-#pragma unroll
-        for (int j = 0; j < NBW; ++j) fw[j] = *reinterpret_cast<const f16x8*>(S + w_off + ColMap<NBW>::blk(j) * 64);
-#pragma unroll
-        for (int i = 0; i < MB; ++i) fa[i] = *reinterpret_cast<const f16x8*>(S + a_off + i * 1024);
-    };
-    auto mm = [&](const f16x8 (&fa)[MB], const f16x8 (&fw)[NBW]) {
-#pragma unroll
-        for (int i = 0; i < MB; ++i)
-#pragma unroll
-            for (int j = 0; j < NBW; ++j)
-                acc[i][j] = GDX_MFMA16(fw[j], fa[i], acc[i][j], 0, 0, 0);
-    };
-    auto step_sync = [&]() {
-        __builtin_amdgcn_sched_barrier(0);
-        wait_vm_h<VM_STEP>();                                     // this wave's pieces of slab g+2 have landed
-        __builtin_amdgcn_s_waitcnt(0xc07f);                       // lgkmcnt(0)
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-    };
-    // One K step: 4 DMA pieces, then 12 fragment reads, spread between the first 20 of the 32 MFMAs.  (Issuing the
-    // DMA among the LAST MFMAs in one of the two waves of a SIMD, to de-phase them, measured 17 % slower: the late
-    // pieces delay that wave's counted wait and with it the barrier.)
-    auto interleave = [&]() {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);    // MFMA
-            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);    // VMEM read (LDS-DMA piece)
-        }
-#pragma unroll
-        for (int r = 0; r < 12; ++r) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);    // DS read
-        }
-        __builtin_amdgcn_sched_group_barrier(0x008, 12, 0);
-    };
-
-#pragma unroll
-    for (int s = 0; s < NST - 1; ++s) issue(s);
-    wait_vm_h<VM_STEP>();                                         // slabs 0 and 1 (of this wave's pieces)
-    __builtin_amdgcn_s_waitcnt(0xc07f);
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    int ks = 0, stage = 0, tile_i = 0, wst = NST - 1;
-    bool skip_wait = false;
-    rd(fa0, fw0, 0);
-    unsigned long long t0 = 0, r0 = 0;
-    if (dbg) { t0 = __builtin_amdgcn_s_memtime(); r0 = __builtin_amdgcn_s_memrealtime(); }
-    // diagnostic stamps (GDX_GEMM_DEBUG only): where a tile's cycles go -- the drain in front of the stores, the stores,
-    // the step pairs right after an epilogue and the steady-state step pairs
-    unsigned long long d_drain = 0, d_store = 0, d_post = 0, d_steady = 0, n_post = 0, n_steady = 0, tp = 0;
-    int since_epi = 100;
-    {
-        for (int g = 0; g < total; g += 2) {
-            if (dbg) tp = __builtin_amdgcn_s_memtime();
-            int nstage = stage == NST - 1 ? 0 : stage + 1;
-            issue(wst);                                           // slab g+NST-1 -> the stage freed by the last barrier
-            wst = wst == NST - 1 ? 0 : wst + 1;
-            rd(fa1, fw1, nstage);
-            mm(fa0, fw0);
-            interleave();
-            if (skip_wait) {                                      // first step of a tile: see the tile-end comment
-                skip_wait = false;
-                __builtin_amdgcn_sched_barrier(0);
-                __builtin_amdgcn_s_waitcnt(0xc07f);
-                __builtin_amdgcn_s_barrier();
-                asm volatile("" ::: "memory");
-                __builtin_amdgcn_sched_barrier(0);
-            } else {
-                step_sync();
-            }
-            stage = nstage;
-            nstage = stage == NST - 1 ? 0 : stage + 1;
-            issue(wst);
-            wst = wst == NST - 1 ? 0 : wst + 1;
-            rd(fa0, fw0, nstage);
-            mm(fa1, fw1);
-            interleave();
-            ks += 2;
-            if (ks == nk) {
-                // Tile end.  The epilogue's global stores share vmcnt with the DMA, and a counted wait behind them would
-                // stall every wave (through the barrier) until the stores retire.  So drain the DMA queue BEFORE the
-                // stores are issued (slabs <= g+3 landed: one slab's latency, once per tile), and let the next step
-                // skip its wait (it needs slab g+3 only).  The step after that waits for "<= 4 outstanding" again:
-                // the 4 pieces of the youngest slab are behind the slab it needs, so the count is only reached once
-                // that slab has landed, whatever order the stores retire in.
-                ks = 0;
-                const int tile = lid + tile_i * G;
-                ++tile_i;
-                __builtin_amdgcn_sched_barrier(0);
-                unsigned long long te0 = 0, te1 = 0;
-                if (dbg) te0 = __builtin_amdgcn_s_memtime();
-                wait_vm_h<0>();
-                __builtin_amdgcn_s_waitcnt(0xc07f);
-                __builtin_amdgcn_s_barrier();
-                asm volatile("" ::: "memory");
-                __builtin_amdgcn_sched_barrier(0);
-                if (dbg) te1 = __builtin_amdgcn_s_memtime();
-                wave_epilogue<MB, NBW>(p, acc, bias_lds, (tile / ntn) * BM + wr * WM, (tile % ntn) * BN + wc * WN, l15, lq);
-                tile_base(tile_i + 1, a_nxt, w_nxt);              // the DMA stream is already inside tile tile_i
-                skip_wait = true;
-                if (dbg) {
-                    const unsigned long long te2 = __builtin_amdgcn_s_memtime();
-                    d_drain += te1 - te0; d_store += te2 - te1;
-                    tp = te2;                                     // the pair's own time ends where the epilogue began
-                    since_epi = -1;
-                }
-            } else {
-                step_sync();
-            }
-            stage = nstage;
-            if (dbg) {
-                const unsigned long long tn = __builtin_amdgcn_s_memtime();
-                if (since_epi >= 0) {
-                    if (since_epi < 2) { d_post += tn - tp; ++n_post; } else { d_steady += tn - tp; ++n_steady; }
-                }
-                ++since_epi;
-            }
-        }
-    }
-    if (dbg && blockIdx.x == 0 && tid == 0) {
-        dbg[6] = d_drain; dbg[7] = d_store; dbg[8] = d_post; dbg[9] = n_post; dbg[10] = d_steady; dbg[11] = n_steady;
-        dbg[12] = (unsigned long long)my_tiles;
-    }
-    if (dbg && blockIdx.x == 0 && tid == 0) {                     // diagnostic stamps (GDX_GEMM_DEBUG)
-        dbg[4] = __builtin_amdgcn_s_memtime() - t0;
-        dbg[5] = __builtin_amdgcn_s_memrealtime() - r0;
-        dbg[3] = (unsigned long long)total;
-    }
-    wait_vm_h<0>();
-#endif
-}
-
-static hipError_t launch_cfg_h8(const GemmHParams& p, int num_cus, hipStream_t s) {
-    constexpr int NST = 4;
-    const size_t lds = (size_t)NST * 32768 + (size_t)p.N * 4;
-    static size_t attr_lds = 0;
-    if (lds > attr_lds) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemmh8_kernel<NST>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        attr_lds = lds;
-    }
-    const int ntm = (p.M + 255) / 256, ntn = p.N / 256;
-    const int ntiles = ntm * ntn;
-    const int grid = ntiles < num_cus ? ntiles : num_cus;
-    hipLaunchKernelGGL((gemmh8_kernel<NST>), dim3(grid), dim3(512), lds, s, p, ntn, ntiles, g2_dbg_buf);
-    return hipGetLastError();
-}
-
-// ---------------------------------------------------------------------------------------------------------------
-// 256 x 256 tile, eight MFMA waves, operands staged as WHOLE 128-byte lines.
+// 256 x 256 tile, eight MFMA waves (2 x 4, each 128 x 64), no dedicated loader waves, operands staged as WHOLE 128-byte lines.
+// Why the tile: on the 128 x 256 kernel above staging is the bound, not the matrix pipe (ablations at M = 66 688, N = 3 072,
+// K = 1 024: MFMA alone 385 us, LDS-DMA alone 518 us); 256 x 256 halves the staged bytes per MFMA, which needs all eight waves
+// computing (8 x 128 accumulators), each issuing its share of the DMA between its MFMAs.
 //
-// What bounds the kernel above (stamps, GDX_GEMM_DEBUG, M = 66 688, N = K = 1 024, clock 1.6 GHz under load): a pair of
+// Its first form (round 1 / 2, removed in round 3: `gemmh8_kernel`, 64-byte LDS rows, one 32-deep K slab per ring stage) was
+// bounded like this (stamps, GDX_GEMM_DEBUG, M = 66 688, N = K = 1 024, clock 1.6 GHz under load): a pair of
 // K steps takes 2 620 cycles in steady state against 2 048 of MFMA issue -- 64 KiB staged per pair = 25 B/clk, the rate
 // the CU's vector-memory pipe sustains for LDS-DMA pieces that take 64 bytes from each of 16 rows (tools/probe/dma_probe:
 // 49 GB/s per CU; 78 GB/s when a piece takes 128 bytes from each of 8 rows, i.e. whole lines).  With 64-byte LDS rows
@@ -721,7 +482,7 @@ static hipError_t launch_cfg_h8(const GemmHParams& p, int num_cus, hipStream_t s
 // c ^ (((r >> 1) ^ (r >> 3)) & 7), which makes every ds_read_b128 lane group touch all 64 banks once for both operands'
 // row maps (searched by brute force over XOR-linear maps; tools/probe notes in DESIGN.md).  For a lane the swizzle is
 // (lane part) ^ (a compile-time even constant K in {0, 2, 4, 6}), so four lane offsets per operand cover every read.
-// Summation order per output element is unchanged (k ascending by 32), so results are bit-identical to the kernel above.
+// Summation order per output element is k ascending by 32, as in the small-tile kernel: bit-identical results whichever runs.
 __global__ __launch_bounds__(512, 1) void gemmh8b_kernel(const GemmHParams p, const int ntn, const int ntiles,
                                                          unsigned long long* dbg) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -875,7 +636,7 @@ __global__ __launch_bounds__(512, 1) void gemmh8b_kernel(const GemmHParams p, co
     unsigned long long t0 = 0, r0 = 0;
     if (dbg) { t0 = __builtin_amdgcn_s_memtime(); r0 = __builtin_amdgcn_s_memrealtime(); }
     const int nbl = wc * WN + lq * CM::QS;                        // this lane's first column inside the tile
-    // diagnostic stamps (GDX_GEMM_DEBUG only), as in the kernel above
+    // diagnostic stamps (GDX_GEMM_DEBUG only)
     unsigned long long d_drain = 0, d_store = 0, d_post = 0, d_steady = 0, n_post = 0, n_steady = 0, tp = 0;
     int since_epi = 100;
     for (int g = 0; g < total; ++g) {
@@ -989,8 +750,7 @@ static hipError_t launch_cfg_hp(const GemmHParams& p, int num_cus, hipStream_t s
 
 template <int MB, int NBW, int NST>
 static hipError_t launch_cfg_h(const GemmHParams& p, int num_cus, hipStream_t s) {
-    static const bool no_pair = getenv("GDX_GEMMH_NOPAIR") != nullptr;   // A/B switch; the stamped diagnostic build is the per-slab one
-    if (no_pair || g2_dbg_buf) return launch_cfg_hp<MB, NBW, NST, false>(p, num_cus, s);
+    if (g2_dbg_buf) return launch_cfg_hp<MB, NBW, NST, false>(p, num_cus, s);   // the stamped diagnostic build is the per-slab one
     return launch_cfg_hp<MB, NBW, NST, true>(p, num_cus, s);
 }
 
@@ -1048,7 +808,7 @@ static GhChoice gh_choose(const GemmHParams& p, int M, int num_cus, int force_mb
     }
     GH_CONFIGS(X)
 #undef X
-    const bool ok8 = p.K >= 128 && p.N % 256 == 0 && (size_t)4 * 32768 + (size_t)p.N * 4 <= 160 * 1024;
+    const bool ok8 = p.K >= 256 && p.N % 256 == 0 && (size_t)4 * 32768 + (size_t)p.N * 4 <= 160 * 1024;
     if (ok8) {
         const double e = force_mb == 16 ? 0.0 : gh_cost(16, 4, M, p.N, p.K, num_cus, p.gelu != 0);
         if ((force_mb == 16 || !force_mb) && e < c.cost) c = GhChoice{e, 16, 4};
@@ -1057,11 +817,7 @@ static GhChoice gh_choose(const GemmHParams& p, int M, int num_cus, int force_mb
 }
 
 static hipError_t launch_gh_choice(const GemmHParams& p, const GhChoice& c, int num_cus, hipStream_t s) {
-    if (c.tmb == 16) {
-        static const bool lines = getenv("GDX_GEMMH8_HALFLINES") == nullptr;   // A/B switch: the 64-byte-row ring
-        if (lines && p.K >= 256) return launch_cfg_h8b(p, num_cus, s);
-        return launch_cfg_h8(p, num_cus, s);
-    }
+    if (c.tmb == 16) return launch_cfg_h8b(p, num_cus, s);
 #define X(mb, nbw, nst) \
     if (c.tmb == mb && c.tnbw == nbw) return launch_cfg_h<mb, nbw, nst>(p, num_cus, s);
     GH_CONFIGS(X)
@@ -1078,7 +834,6 @@ hipError_t launch_gemmh(const GemmHParams& p, hipStream_t s) {
         if (const char* e = getenv("GDX_GEMMH_TILE")) sscanf(e, "%d,%d", &force_mb, &force_nbw);
     }
     static const bool debug = getenv("GDX_GEMM_DEBUG") != nullptr;
-    static const bool no_split = getenv("GDX_GEMMH_NOSPLIT") != nullptr;      // A/B switch
     const bool gelu = p.gelu != 0;
     const GhChoice whole = gh_choose(p, p.M, num_cus, force_mb, force_nbw);
     if (!whole.tmb) return hipErrorNotSupported;
@@ -1090,7 +845,7 @@ hipError_t launch_gemmh(const GemmHParams& p, hipStream_t s) {
     // 159.3 -> 151.4 us; N = 3 072: unchanged, 420 us -- profiles/r02e_fp16_gemm_bound.txt).  Every output element is
     // still one k-ascending sum (see the headers), so the cut does not change a single bit.  It needs the plain row-major
     // epilogue (no token-row map, no per-sample vector: those index by the absolute row).
-    if (whole.tmb == 16 && !no_split && !force_mb && !p.rowmap && !p.V) {
+    if (whole.tmb == 16 && !force_mb && !p.rowmap && !p.V) {
         const int ntn = p.N / 256, ntm = (p.M + 255) / 256;
         const long tiles = (long)ntm * ntn, full = tiles / num_cus;
         const int m_main = (int)(full * num_cus / ntn) * 256;

@@ -638,8 +638,7 @@ hipError_t launch_local_attention(const float* xseq, const float* cosT, const fl
                                   _Float16* enc16_, int B, int T, int d, int heads, int window, hipStream_t s) {
     half_t* enc16 = reinterpret_cast<half_t*>(enc16_);
     const int e = d / heads;
-    static const bool scalar_only = getenv("GDX_LOCAL_ATTN_SCALAR") != nullptr;      // A/B switch
-    if (!scalar_only && (e == 32 || e == 64 || e == 128) && window >= 1 && window <= 16 && d % 4 == 0) {
+    if ((e == 32 || e == 64 || e == 128) && window >= 1 && window <= 16 && d % 4 == 0) {
         const int nwork = B * heads * (T / window);
         const dim3 grid((nwork + 3) / 4), block(256);
         if (e == 128)

@@ -77,7 +77,15 @@ class LossType(enum.Enum):
         return self == LossType.KL or self == LossType.RESCALED_KL
 
 
-NOISE_BLOCK = 50        # steps of torch-generator noise drawn ahead of one gdx_sample_loop call (rng="torch")
+NOISE_BLOCK = 50        # most steps of torch-generator noise drawn ahead of one gdx_sample_loop call (rng="torch") ...
+NOISE_BLOCK_BYTES = 256 << 20   # ... within this many bytes of tape (660 MB at config 2 and 6.6 GB at config 5 otherwise)
+
+
+def noise_block_steps(n_steps, per_step_elems):
+    """Steps of pre-drawn noise per gdx_sample_loop call: at most NOISE_BLOCK, at most NOISE_BLOCK_BYTES of fp32 tape, at least one.
+    Blocks are issued back to back without a host synchronisation, so smaller blocks cost nothing measurable."""
+    by_bytes = NOISE_BLOCK_BYTES // max(1, 4 * int(per_step_elems))
+    return max(1, min(int(n_steps), NOISE_BLOCK, by_bytes))
 
 
 def _is_native(model):
@@ -211,6 +219,70 @@ class GaussianDiffusion:
         coef = self.coef_table(GDX_SAMPLER_P, x_start.device)
         tv = E.require_device(t, "t").reshape(-1).to(th.int64).contiguous()
         return E.q_sample_t(E.f32c(x_start, "x_start"), E.f32c(noise, "noise"), coef, tv)
+
+    def _expand(self, table, t, like):
+        """_extract_into_tensor (reference :1595-1608): fp64 table -> gather -> .float() -> expanded view of `like`'s shape."""
+        return th.from_numpy(np.ascontiguousarray(table, dtype=np.float64)).to(like.device)[t].float().view(
+            -1, *([1] * (like.dim() - 1))).expand(like.shape)
+
+    def q_mean_variance(self, x_start, t):
+        """q(x_t | x_0) (reference :216-231): (mean, variance, log_variance), all of x_start's shape.  The mean is the q_sample
+        kernel with zero noise (a * x_start + b * 0); the two variance entries are per-sample table values."""
+        E.require_device(x_start, "x_start")
+        xs = E.f32c(x_start, "x_start")
+        tv = E.require_device(t, "t").reshape(-1).to(th.int64).contiguous()
+        mean = E.q_sample_t(xs, th.zeros_like(xs), self.coef_table(GDX_SAMPLER_P, xs.device), tv)
+        return mean, self._expand(1.0 - self.alphas_cumprod, tv, xs), self._expand(self.log_one_minus_alphas_cumprod, tv, xs)
+
+    def q_posterior_mean_variance(self, x_start, x_t, t):
+        """q(x_{t-1} | x_t, x_0) (reference :253-275): (posterior_mean, posterior_variance, posterior_log_variance_clipped).
+        The mean is the fused update kernel's coef1 * x_start + coef2 * x_t with zero noise weight."""
+        assert x_start.shape == x_t.shape
+        E.require_device(x_t, "x_t")
+        xt, xs = E.f32c(x_t, "x_t"), E.f32c(x_start, "x_start")
+        tv = E.require_device(t, "t").reshape(-1).to(th.int64).contiguous()
+        mean = th.empty_like(xt)
+        E.sampler_update(GDX_SAMPLER_P, self._posterior_table(xt.device), xt, xs, mean, t=tv, noise=th.zeros_like(xt))
+        var, logvar = self._expand(self.posterior_variance, tv, xt), self._expand(self.posterior_log_variance_clipped, tv, xt)
+        assert mean.shape[0] == var.shape[0] == logvar.shape[0] == x_start.shape[0]
+        return mean, var, logvar
+
+    def _posterior_table(self, device):
+        """Ancestral coefficient rows with the POSTERIOR variance whatever model_var_type says (q_posterior_mean_variance is a
+        property of the forward process; only columns 0 / 1 are used with zero noise)."""
+        key = ("posterior", str(device))
+        if key not in self._coef_cache:
+            f32 = lambda a: th.from_numpy(np.ascontiguousarray(a, dtype=np.float64)).float()   # noqa: E731
+            c = th.zeros(self.num_timesteps, 8, dtype=th.float32)
+            c[:, 0], c[:, 1] = f32(self.posterior_mean_coef1), f32(self.posterior_mean_coef2)
+            self._coef_cache[key] = c.to(device)
+        return self._coef_cache[key]
+
+    def condition_mean(self, cond_fn, p_mean_var, x, t, model_kwargs=None):
+        """Sohl-Dickstein conditioning (reference :418-433): p_mean_var["mean"] + p_mean_var["variance"] * cond_fn(x, t, ...).
+        The product / sum run in the fused update kernel (identity mean rows: 1 * mean + 0 * x, then + variance * gradient,
+        zero noise weight).  The variance is this diffusion's model variance at t -- what p_mean_variance put into the dict."""
+        grad = E.f32c(self._call_cond_fn(cond_fn, x, t, model_kwargs or {}), "cond_fn gradient")
+        mean = E.f32c(p_mean_var["mean"], "p_mean_var['mean']")
+        assert grad.shape == mean.shape == x.shape
+        tv = E.require_device(t, "t").reshape(-1).to(th.int64).contiguous()
+        out = th.empty_like(mean)
+        E.sampler_update(GDX_SAMPLER_P, self._identity_mean_table(mean.device), E.f32c(x, "x"), mean, out, t=tv,
+                         noise=th.zeros_like(mean), cond_grad=grad)
+        return out
+
+    def condition_score(self, cond_fn, p_mean_var, x, t, model_kwargs=None):
+        """Song et al. conditioning (reference :448-472): eps <- eps - sqrt(1 - alpha_bar) * cond_fn(x, t, ...), pred_xstart from
+        it (gdx_plms_update kind 7), mean = posterior mean of the new pred_xstart.  Returns a copy of the dict."""
+        xc = E.f32c(x, "x")
+        grad = E.f32c(self._call_cond_fn(cond_fn, x, t, model_kwargs or {}), "cond_fn gradient")
+        tv = E.require_device(t, "t").reshape(-1).to(th.int64).contiguous()
+        out = dict(p_mean_var)
+        out["pred_xstart"] = E.plms_update(7, self.coef_table(GDX_SAMPLER_DDIM, xc.device), tv, xc,
+                                           E.f32c(p_mean_var["pred_xstart"], "pred_xstart"),
+                                           eps=(grad, self._cond_coef(xc.device)))
+        out["mean"], _, _ = self.q_posterior_mean_variance(x_start=out["pred_xstart"], x_t=xc, t=tv)
+        return out
 
     # ------------------------------------------------------------------ one reverse step
     def _scale_timesteps(self, t):
@@ -428,7 +500,7 @@ class GaussianDiffusion:
         if self.rescale_timesteps:
             raise NotImplementedError("rescale_timesteps=True is not used by the reference's sampler configuration")
         draw = tape is None and rng == "torch"
-        block = min(n, NOISE_BLOCK) if (draw or progress) else n
+        block = noise_block_steps(n, (1 if const_noise else B) * J * F * T) if draw else (min(n, NOISE_BLOCK) if progress else n)
         bar = None
         if progress:
             from tqdm.auto import tqdm

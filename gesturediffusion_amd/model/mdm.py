@@ -137,6 +137,14 @@ class EncoderParams(nn.Module):
         self.num_layers = num_layers
 
 
+def _norm_dev(device):
+    """torch.device with an explicit index ('cuda' -> the current device)."""
+    d = torch.device(device)
+    if d.type == "cuda" and d.index is None and torch.cuda.is_available():
+        d = torch.device("cuda", torch.cuda.current_device())
+    return d
+
+
 class _NativeDenoiser(nn.Module):
     """Shared engine plumbing of MDM and MDM_Old."""
 
@@ -161,13 +169,21 @@ class _NativeDenoiser(nn.Module):
         key = tuple((k, v.data_ptr(), v._version) for k, v in named.items())
         eng = self.__dict__.get("_eng")
         dtype = getattr(self, "compute_dtype", None) or os.environ.get("GDX_COMPUTE_DTYPE", "fp32")
+        if self.__dict__.get("_packed_image"):
+            # weights came from load_packed(): the module's own parameters are NOT the model (they were never loaded), so
+            # nothing may be re-packed from them behind the caller's back
+            if eng is None or eng.compute_dtype != dtype:
+                raise GdxError(f"the weights came from a packed image built for compute_dtype "
+                               f"{eng.compute_dtype if eng is not None else '?'!r}; reload the checkpoint (load_state_dict / "
+                               f"load_model_cached) to run in {dtype!r}")
+            if _norm_dev(device) != self.__dict__.get("_packed_device"):
+                raise GdxError(f"the packed image was uploaded to {self.__dict__.get('_packed_device')} but the input is on "
+                               f"{device}; load it again on that device")
+            return eng
         if eng is not None and eng.compute_dtype != dtype:
             eng = None
-            self.__dict__["_packed_image"] = False
         if eng is None:
             eng = self._new_engine(dtype)
-        if self.__dict__.get("_packed_image"):
-            return eng                     # weights came from load_packed(): the module's own parameters are not the model
         if self.__dict__["_eng_key"] != key:
             for k, v in named.items():
                 if v.device != device:
@@ -188,14 +204,17 @@ class _NativeDenoiser(nn.Module):
 
     def load_packed(self, blob, device):
         """Take the weights from a packed image instead of a state dict.  The module's nn.Parameters are left as they are
-        and are ignored from here on (state_dict() does NOT describe the loaded model); load_state_dict() or a change of
-        compute_dtype switches back to them.  Raises GdxError if the image was built for another configuration."""
+        and are ignored from here on (state_dict() does NOT describe the loaded model); load_state_dict() switches back to
+        them.  Changing compute_dtype (or the device) afterwards raises GdxError at the next call: the image holds one
+        dtype's operands and the untouched parameters must not be packed in its place.  Raises GdxError if the image was
+        built for another configuration."""
         dtype = getattr(self, "compute_dtype", None) or os.environ.get("GDX_COMPUTE_DTYPE", "fp32")
         eng = self.__dict__.get("_eng")
         if eng is None or eng.compute_dtype != dtype:
             eng = self._new_engine(dtype)
         eng.import_packed(blob, torch.device(device))
         self.__dict__["_packed_image"] = True
+        self.__dict__["_packed_device"] = _norm_dev(device)
 
     def load_state_dict(self, *args, **kwargs):
         self.__dict__["_packed_image"] = False

@@ -92,9 +92,11 @@ int gdx_weights_ready(gdx_handle_t h);
  * start.  gdx_set_weight turns each tensor into the kernels' operand layout (zero-padded K-contiguous panels, their fp16
  * twins in the fp16 mode, padded bias / LayerNorm vectors, positional and rotary tables); these three calls move that
  * whole layout out of and into a handle as ONE host blob, so a caller can keep it next to the checkpoint and skip the
- * per-tensor path.  The blob starts with a magic and the gdx_config_t it was built for; gdx_import_packed refuses
- * (and leaves the handle untouched) unless the configuration, the compute dtype and every record's dimensions match
- * what this handle computes for itself.  After a successful import gdx_weights_ready() holds.
+ * per-tensor path.  The blob starts with a magic, the gdx_config_t it was built for and a 64-bit checksum of its payload;
+ * gdx_import_packed refuses (and leaves the handle untouched) unless the configuration, the compute dtype, every record's
+ * dimensions and the checksum match what this handle computes for itself.  Once validation has passed the upload starts and
+ * the handle counts as "weights not set" until it has completed: a failed allocation or copy leaves gdx_weights_ready()
+ * failing, never a half-uploaded model.  After a successful import gdx_weights_ready() holds.
  *   gdx_packed_bytes : size of the blob for this handle (all weights must be set)
  *   gdx_export_packed: fill `host` (exactly that many bytes); synchronises `stream`
  *   gdx_import_packed: upload a blob; synchronises `stream` (the caller may free `host` on return) */
@@ -296,7 +298,7 @@ int gdx_profile_end(gdx_handle_t h, float* avg_us, int32_t* launches);
  * (0 bias, 1 bias+GELU, 2 bias+residual) on scratch buffers filled with N(0,1). */
 int gdx_bench_gemm(int32_t M, int32_t N, int32_t K, int32_t epi, int32_t iters, float* avg_us, void* stream);
 /* Time `iters` launches of the self-attention core on scratch qkv [B*S][3d] (version 1 = attention.hip,
- * 2 = attention2.hip where supported, 3 = the fp16 kernel attentionh.hip, 4 = attention3.hip where supported). */
+ * 3 = the fp16 kernel attentionh.hip, 4 = attention3.hip where supported). */
 int gdx_bench_attention(int32_t B, int32_t S, int32_t H, int32_t d, int32_t version, int32_t iters,
                         float* avg_us, void* stream);
 /* ---- reduced-precision building blocks (tests / measurement) ---------------------------- */
@@ -316,7 +318,7 @@ int gdx_attention_f16(const float* qkv, float* ctx, int32_t B, int32_t S, int32_
 int gdx_set_test_half_dtype(int32_t dtype);
 /* ctx = softmax(Q K^T / sqrt(hd)) V per (sample, head) through the fp32 attention kernels: the SDPA inside
  * nn.MultiheadAttention of the encoder layers (model/mdm.py:90-96).  qkv [B*S][3d], ctx [B*S][d] fp32 device arrays.
- * version 0 = the choice gdx_forward makes, 1 = 32x32-block kernel (attention.hip), 2 = attention2.hip,
+ * version 0 = the choice gdx_forward makes, 1 = 32x32-block kernel (attention.hip, the general fallback),
  * 3 = attention3.hip, 5 = attention3.hip's persistent variant on ceil(B*H / 3) workgroups.  Test entry point: works on
  * a padded scratch copy and synchronises the stream. */
 int gdx_attention_f32(const float* qkv, float* ctx, int32_t B, int32_t S, int32_t H, int32_t d, int32_t version,

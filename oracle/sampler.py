@@ -279,3 +279,27 @@ def cond_xstart(tab, x0, x, t, grad):
     """pred_xstart under condition_score (:452-472)."""
     eps = predict_eps(tab, x0, x, t) - (1 - extract(tab.alphas_cumprod, t)).sqrt() * grad
     return predict_xstart(tab, eps, x, t)
+
+
+# ---------------------------------------------------------------------------------------------
+# public helper methods of GaussianDiffusion (reference :216-231, :253-275, :418-433, :448-472)
+def q_mean_variance(tab, x_start, t):
+    shape = x_start.shape
+    return (extract(tab.sqrt_alphas_cumprod, t) * x_start, extract(1.0 - tab.alphas_cumprod, t).expand(shape),
+            extract(tab.log_one_minus_alphas_cumprod, t).expand(shape))
+
+
+def q_posterior_mean_variance(tab, x_start, x_t, t):
+    shape = x_t.shape
+    mean = extract(tab.posterior_mean_coef1, t) * x_start + extract(tab.posterior_mean_coef2, t) * x_t
+    return mean, extract(tab.posterior_variance, t).expand(shape), extract(tab.posterior_log_variance_clipped, t).expand(shape)
+
+
+def condition_mean(mean, variance, grad):
+    return mean.float() + variance * grad.float()
+
+
+def condition_score(tab, pred_xstart, x, t, grad):
+    """-> (pred_xstart, mean) of the dict condition_score returns."""
+    x0c = cond_xstart(tab, pred_xstart, x, t, grad)
+    return x0c, q_posterior_mean_variance(tab, x0c, x, t)[0]

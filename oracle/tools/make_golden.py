@@ -417,6 +417,37 @@ def gen_guided_tiny(mods, out):
         np.savez_compressed(os.path.join(out, f"guided_{arch}_tiny.npz"), **d)
 
 
+def helper_inputs(n_steps):
+    """Inputs of the public helper methods: pose-shaped tensors, per-sample timesteps incl. 0 and the last step."""
+    g = torch.Generator().manual_seed(77)
+    shape = (4, 16, 1, 20)
+    x_start, x_t, pred = (torch.randn(shape, generator=g) for _ in range(3))
+    t = torch.tensor([0, 1, n_steps // 2, n_steps - 1])
+    return x_start, x_t, pred, t
+
+
+def gen_helpers(mods, out):
+    """q_mean_variance (:216), q_posterior_mean_variance (:253), condition_mean (:418), condition_score (:448) of the reference's
+    GaussianDiffusion / SpacedDiffusion, on the full schedule and on a 20-step respacing (cond_fn then sees mapped timesteps)."""
+    gd, rs = mods[3], mods[4]
+    d = {}
+    for tag, resp in (("full", ""), ("r20", [20])):
+        df = make_diffusion(gd, rs, resp)
+        x_start, x_t, pred, t = helper_inputs(df.num_timesteps)
+        qm = df.q_mean_variance(x_start, t)
+        qp = df.q_posterior_mean_variance(x_start, x_t, t)
+        for i, nm in enumerate(("mean", "variance", "log_variance")):
+            d[f"{tag}_qmv_{nm}"] = qm[i].numpy().copy()
+            d[f"{tag}_qpost_{nm}"] = qp[i].numpy().copy()
+        pmv = {"mean": qp[0], "variance": qp[1], "log_variance": qp[2], "pred_xstart": pred}
+        d[f"{tag}_condition_mean"] = df.condition_mean(cond_fn_fixture, pmv, x_t, t, model_kwargs={}).numpy().copy()
+        cs = df.condition_score(cond_fn_fixture, pmv, x_t, t, model_kwargs={})
+        d[f"{tag}_condition_score_pred_xstart"] = cs["pred_xstart"].numpy().copy()
+        d[f"{tag}_condition_score_mean"] = cs["mean"].numpy().copy()
+        assert cs["variance"] is pmv["variance"]
+    np.savez_compressed(os.path.join(out, "helpers.npz"), **d)
+
+
 def gen_losses_tiny(mods, out):
     """training_losses (gaussian_diffusion.py:1227-1352), forward values only, on the tiny models: per-sample timesteps,
     explicit noise, a ragged frame mask.  The reference reads `model.model` (its DDP / CFG wrapper convention)."""
@@ -608,12 +639,12 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--ref", default="/root/reference")
     ap.add_argument("--out", default=os.path.join(REPO, "tests", "golden"))
-    ap.add_argument("--only", default="", help="comma-separated subset: schedule,forward,loops,plms,losses,guided,clip,meantypes,collate,chunks,real,negative,keys")
+    ap.add_argument("--only", default="", help="comma-separated subset: schedule,forward,loops,plms,losses,guided,helpers,clip,meantypes,collate,chunks,real,negative,keys")
     args = ap.parse_args()
     os.makedirs(args.out, exist_ok=True)
     torch.set_num_threads(8)
     mods = import_reference(args.ref)
-    gens = {"schedule": gen_schedule, "forward": gen_forward_tiny, "loops": gen_loops_tiny, "plms": gen_plms_tiny, "losses": gen_losses_tiny, "guided": gen_guided_tiny, "clip": gen_clip_tiny, "meantypes": gen_meantypes_tiny,
+    gens = {"schedule": gen_schedule, "forward": gen_forward_tiny, "loops": gen_loops_tiny, "plms": gen_plms_tiny, "losses": gen_losses_tiny, "guided": gen_guided_tiny, "helpers": gen_helpers, "clip": gen_clip_tiny, "meantypes": gen_meantypes_tiny,
             "collate": gen_collate, "chunks": gen_chunks_tiny, "real": gen_real_shapes, "negative": gen_negative, "keys": gen_state_dict_keys}
     for name in (args.only.split(",") if args.only else gens):
         gens[name](mods, args.out)

@@ -571,7 +571,7 @@ def test_packed_image_roundtrip_is_bit_exact(arch, dtype):
     out_a, out_b = _forward(a, cfg, compute_dtype=dtype), _forward(b, cfg, compute_dtype=dtype)
     assert not torch.equal(out_a, out_b)
     blob = a.export_packed(dev())
-    assert blob[:8] == b"GDXPACK2" and len(blob) > 4 * sum(p.numel() for p in a.parameters())
+    assert blob[:8] == b"GDXPACK3" and len(blob) > 4 * sum(p.numel() for p in a.parameters())
     b.load_packed(blob, dev())
     assert torch.equal(_forward(b, cfg), out_a)                     # bit for bit
     assert torch.equal(_forward(b, cfg, B=2, T=30), _forward(a, cfg, B=2, T=30))   # survives a re-prepare

@@ -364,3 +364,13 @@ def test_stated_tolerance_under_guidance():
     assert stated_tolerance("bf16", 2.5) == pytest.approx(8e-2) and stated_tolerance("fp32", None, loop=False) == 1e-4
     with pytest.raises(ValueError):
         stated_tolerance("fp8")
+
+
+def test_noise_block_is_sized_by_bytes():
+    """The torch-generator seam pre-draws at most 256 MiB of noise per block (config 2: 50 x 13.2 MB would be 660 MB)."""
+    from gesturediffusion_amd.diffusion.gaussian_diffusion import NOISE_BLOCK, NOISE_BLOCK_BYTES, noise_block_steps
+    assert noise_block_steps(1000, 2 * 16 * 20) == NOISE_BLOCK                      # tiny tensors: the step cap
+    c2 = noise_block_steps(1000, 64 * 263 * 196)
+    assert c2 == NOISE_BLOCK_BYTES // (4 * 64 * 263 * 196) == 20 and c2 * 4 * 64 * 263 * 196 <= NOISE_BLOCK_BYTES
+    assert noise_block_steps(1000, 128 * 498 * 520) == 2                            # config 5
+    assert noise_block_steps(1000, 10 ** 10) == 1 and noise_block_steps(7, 10) == 7

@@ -419,3 +419,24 @@ def test_negative_cases(golden_dir):
     x, seedp, mfcc = synthetic_inputs(cfg, 2, 20, seed=3)
     with pytest.raises(KeyError):
         omf.forward(p, cfg, x, torch.tensor([1, 2]), {"mfcc": mfcc})
+
+
+@pytest.mark.parametrize("tag,resp", [("full", ""), ("r20", [20])])
+def test_public_helper_methods_vs_reference(tag, resp):
+    """q_mean_variance / q_posterior_mean_variance / condition_mean / condition_score of the reference's diffusion object
+    (helpers.npz, oracle/tools/make_golden.py::gen_helpers): the oracle's restatements are bit-exact."""
+    sys.path.insert(0, os.path.join(REPO, "oracle", "tools"))
+    from make_golden import helper_inputs
+    g = load_golden("helpers.npz")
+    tab, tmap = osch.make_tables("cosine", 1000, resp)
+    x_start, x_t, pred, t = helper_inputs(tab.num_timesteps)
+    qm = osamp.q_mean_variance(tab, x_start, t)
+    qp = osamp.q_posterior_mean_variance(tab, x_start, x_t, t)
+    for i, nm in enumerate(("mean", "variance", "log_variance")):
+        assert np.array_equal(qm[i].numpy(), g[f"{tag}_qmv_{nm}"]), nm
+        assert np.array_equal(qp[i].numpy(), g[f"{tag}_qpost_{nm}"]), nm
+    grad = cond_fn_fixture(x_t, torch.tensor(tmap)[t])
+    assert np.array_equal(osamp.condition_mean(qp[0], qp[1], grad).numpy(), g[f"{tag}_condition_mean"])
+    x0c, mean = osamp.condition_score(tab, pred, x_t, t, grad)
+    assert np.array_equal(x0c.numpy(), g[f"{tag}_condition_score_pred_xstart"])
+    assert np.array_equal(mean.numpy(), g[f"{tag}_condition_score_mean"])
