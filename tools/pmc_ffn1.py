@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
-"""Summarise the --pmc passes of tools/profile_round.sh: python tools/pmc_ffn1.py gpurun_out/<tag>
+"""Summarise the --pmc passes of tools/profile_round.sh: python tools/pmc_ffn1.py gpurun_out/<tag> [configs...]
 Per config: the FFN-1 GEMM's FETCH_SIZE / WRITE_SIZE per launch (FETCH doubled: gfx950 reports half the bytes of 16-B/lane
 streaming reads, MI355X_MICROARCH.md, HBM), and matrix-pipe busy cycles per SIMD / kernel duration for the top kernels.
-Config 2 (fp32): FFN-1 is its own template instantiation (the gemm4 kernel launched L times per step with GELU).
-Config 5 (fp16): every encoder GEMM is gemmh8b_kernel (+ a small-tile launch for the last rows); FFN-1 is the one dispatched
+fp32 configs (1, 2, 3, 4, genea): FFN-1 is its own template instantiation (the gemm4 kernel launched L times per step with GELU).
+Config 5 / 5b16 (fp16): every encoder GEMM is gemmh8b_kernel (+ a small-tile launch for the last rows); FFN-1 is the one dispatched
 right after a LayerNorm and followed by another GEMM (FFN-2) rather than by attention."""
 import csv, glob, json, os, sys, collections
 root = sys.argv[1]
@@ -26,29 +26,26 @@ def per_dispatch(rs, counter):
 def ffn1_groups(seq, cfg):
     """index lists: the dispatches that make up one FFN-1 launch"""
     out = []
-    if cfg == "2":
-        cnt = collections.Counter(n for n, _, _ in seq if "gemm4_kernel" in n)
-        # FFN-1 = the gemm4 instantiation with exactly as many calls as the attention kernel and the largest avg value among those
-        att = sum(1 for n, _, _ in seq if "attention3" in n)
-        cands = [n for n, c in cnt.items() if c == att]
-        # QKV and FFN-1 both have `att` calls and both follow a LayerNorm
-        for i, (n, _, _) in enumerate(seq):          # ... and is followed by FFN-2 (a GEMM), QKV by attention
-            if n in cands and 0 < i < len(seq) - 1 and "layernorm" in seq[i - 1][0] and "gemm4_kernel" in seq[i + 1][0]:
+    if not cfg.startswith("5"):
+        # QKV and FFN-1 both follow a LayerNorm; FFN-1 is followed by FFN-2 (a GEMM), QKV by attention
+        for i, (n, _, _) in enumerate(seq):
+            if "gemm4_kernel" in n and 0 < i < len(seq) - 1 and "layernorm" in seq[i - 1][0] and "gemm4_kernel" in seq[i + 1][0]:
                 out.append([i])
         return out
+    isg = lambda n: "gemmh8b" in n or "gemmh_kernel" in n        # noqa: E731
     for i, (n, _, _) in enumerate(seq):
-        if "gemmh8b" in n and i > 0 and "layernorm" in seq[i - 1][0]:
+        if isg(n) and i > 0 and "layernorm" in seq[i - 1][0]:
             g = [i]
             j = i + 1
-            if j < len(seq) and "gemmh_kernel" in seq[j][0]:
-                g.append(j); j += 1
-            if j < len(seq) and "gemmh8b" in seq[j][0]:      # followed by FFN-2, not by attention (that would be QKV)
+            if "gemmh8b" in n and j < len(seq) and "gemmh_kernel" in seq[j][0]:
+                g.append(j); j += 1                                # row-cut tail launch of the same GEMM (follows a 256 x 256 main only)
+            if j < len(seq) and isg(seq[j][0]):                    # followed by FFN-2, not by attention (that would be QKV)
                 out.append(g)
     return out
 
 
 res = {}
-for cfg in ("2", "5"):
+for cfg in (sys.argv[2:] or ["2", "5"]):
     ent = {}
     for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
         seq = per_dispatch(rows(os.path.join(root, f"pmc_{ctr}_c{cfg}")), ctr)
