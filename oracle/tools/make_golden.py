@@ -440,6 +440,9 @@ def gen_helpers(mods, out):
             d[f"{tag}_qmv_{nm}"] = qm[i].numpy().copy()
             d[f"{tag}_qpost_{nm}"] = qp[i].numpy().copy()
         pmv = {"mean": qp[0], "variance": qp[1], "log_variance": qp[2], "pred_xstart": pred}
+        # the gradient itself is part of the fixture: torch.sin is not bit-reproducible across CPUs (vectorised libm variants),
+        # the four methods under test only consume it
+        d[f"{tag}_grad"] = cond_fn_fixture(x_t, torch.tensor(df.timestep_map)[t]).numpy().copy()
         d[f"{tag}_condition_mean"] = df.condition_mean(cond_fn_fixture, pmv, x_t, t, model_kwargs={}).numpy().copy()
         cs = df.condition_score(cond_fn_fixture, pmv, x_t, t, model_kwargs={})
         d[f"{tag}_condition_score_pred_xstart"] = cs["pred_xstart"].numpy().copy()
