@@ -134,7 +134,9 @@ def _cond_fn(x, t, **kwargs):
 def test_public_helper_methods_bit_exact_vs_oracle_and_reference(tag, resp):
     """q_mean_variance, q_posterior_mean_variance, condition_mean, condition_score (reference
     diffusion/gaussian_diffusion.py:216, 253, 418, 448) as methods of the drop-in diffusion object, on the device: bit-equal to
-    the oracle's restatements AND to the reference's own outputs (tests/golden/helpers.npz), same tuple / dict shapes."""
+    the oracle's restatements (run on this box), same tuple / dict shapes; against the reference's own outputs
+    (tests/golden/helpers.npz, bit-equal to the oracle where they were generated: tests/test_oracle_golden.py) to 2e-6 -- the fp64
+    schedule tables come from libm's cos, whose last bit depends on the host CPU, and at t = 999 the coefficients are 2e4."""
     sys.path.insert(0, os.path.join(REPO, "oracle", "tools"))
     from conftest import load_golden
     from make_golden import helper_inputs
@@ -151,7 +153,7 @@ def test_public_helper_methods_bit_exact_vs_oracle_and_reference(tag, resp):
     for i, nm in enumerate(("mean", "variance", "log_variance")):
         assert qm[i].shape == qp[i].shape == xs.shape
         assert torch.equal(qm[i].cpu(), want_m[i]) and torch.equal(qp[i].cpu(), want_p[i]), nm
-        assert np.array_equal(qm[i].cpu().numpy(), g[f"{tag}_qmv_{nm}"]) and np.array_equal(qp[i].cpu().numpy(), g[f"{tag}_qpost_{nm}"])
+        assert rel_err(qm[i].cpu(), g[f"{tag}_qmv_{nm}"]) < 2e-6 and rel_err(qp[i].cpu(), g[f"{tag}_qpost_{nm}"]) < 2e-6
     pmv = {"mean": qp[0], "variance": qp[1], "log_variance": qp[2], "pred_xstart": pr}
     # the gradient is the CALLER's arithmetic (torch.sin differs in the last bit between the GPU and CPUs, and between CPUs):
     # the fixture carries the gradient the reference run used; the callable hands those bits out and still checks that it
@@ -166,14 +168,14 @@ def test_public_helper_methods_bit_exact_vs_oracle_and_reference(tag, resp):
         return grad.to(x.device)
     cm = df.condition_mean(cond_fn, pmv, xt, td, model_kwargs={})
     assert torch.equal(cm.cpu(), osamp.condition_mean(want_p[0], want_p[1], grad))
-    assert np.array_equal(cm.cpu().numpy(), g[f"{tag}_condition_mean"])
+    assert rel_err(cm.cpu(), g[f"{tag}_condition_mean"]) < 2e-6
     cs = df.condition_score(cond_fn, pmv, xt, td, model_kwargs={})
     assert len(seen) == 2 and all(torch.equal(ts, torch.tensor(tmap)[t]) for ts in seen)
     x0c, mean = osamp.condition_score(tab, pred, x_t, t, grad)
     assert set(cs) == set(pmv) and cs["variance"] is pmv["variance"] and pmv["pred_xstart"] is pr
     assert torch.equal(cs["pred_xstart"].cpu(), x0c) and torch.equal(cs["mean"].cpu(), mean)
-    assert np.array_equal(cs["pred_xstart"].cpu().numpy(), g[f"{tag}_condition_score_pred_xstart"])
-    assert np.array_equal(cs["mean"].cpu().numpy(), g[f"{tag}_condition_score_mean"])
+    assert rel_err(cs["pred_xstart"].cpu(), g[f"{tag}_condition_score_pred_xstart"]) < 2e-6
+    assert rel_err(cs["mean"].cpu(), g[f"{tag}_condition_score_mean"]) < 2e-6
 
 
 # ------------------------------------------------------------------------------------------------ packed image hardening
