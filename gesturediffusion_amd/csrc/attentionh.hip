@@ -45,6 +45,15 @@ typedef __fp16 fp16x4_t __attribute__((__vector_size__(4 * sizeof(__fp16))));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
+// Logical workgroup id with the workgroups of one XCD contiguous (blocks b, b + 8, b + 16, ... share an XCD and its L2; bijective
+// for any grid size, as in gemm2.hip).  The query chunks of one (sample, head) are consecutive items and read the same K / V:
+// numbered this way they run on ONE XCD at about the same time, so the K / V tiles are fetched into that L2 once instead of once
+// per chunk through three different L2s (round 3).
+__device__ __forceinline__ int ah_xcd_lid(int bid, int G) {
+    const int q = G >> 3, r = G & 7, xcd = bid & 7, idx = bid >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+
 template <int N>
 __device__ __forceinline__ void ah_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
@@ -78,8 +87,9 @@ __global__ __launch_bounds__(512, 1) void attentionh8_kernel(const _Float16* __r
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid) >> 6;
     const int l15 = lane & 15, lq = lane >> 4;
-    const int ci = blockIdx.x % nchunk;
-    const int h = (blockIdx.x / nchunk) % H, b = blockIdx.x / (nchunk * H);
+    const int wg = ah_xcd_lid((int)blockIdx.x, (int)gridDim.x);
+    const int ci = wg % nchunk;
+    const int h = (wg / nchunk) % H, b = wg / (nchunk * H);
     const long ld = 3L * d;
     const long base_off = (long)b * S * ld + h * HD;
     const _Float16* base = qkv + base_off;
@@ -258,8 +268,9 @@ __global__ __launch_bounds__(512, 1) void attentionh8q_kernel(const _Float16* __
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid) >> 6;
     const int l15 = lane & 15, lq = lane >> 4;
-    const int ci = blockIdx.x % nchunk;
-    const int h = (blockIdx.x / nchunk) % H, b = blockIdx.x / (nchunk * H);
+    const int wg = ah_xcd_lid((int)blockIdx.x, (int)gridDim.x);
+    const int ci = wg % nchunk;
+    const int h = (wg / nchunk) % H, b = wg / (nchunk * H);
     const long ld = 3L * d;
     const long base_off = (long)b * S * ld + h * HD;
     const _Float16* base = qkv + base_off;
@@ -468,12 +479,13 @@ __global__ __launch_bounds__(512, 1) void attentionh8p_kernel(const _Float16* __
     const int nqb = (S + 15) / 16;
     const int ntiles = (S + 31) / 32;
     const int G = gridDim.x;
-    const int my_items = (int)blockIdx.x < nitems ? (nitems - (int)blockIdx.x + G - 1) / G : 0;
+    const int lid = ah_xcd_lid((int)blockIdx.x, G);
+    const int my_items = lid < nitems ? (nitems - lid + G - 1) / G : 0;
     if (my_items == 0) return;
     auto fswz = [](int row) { return HD == 32 ? ((row >> 2) & 1) << 1 : HD == 64 ? ((row >> 1) & 3) << 1 : (row & 7) << 1; };
     // item i of this workgroup -> element offset of its (sample, head) inside qkv
     auto item_off = [&](int i) -> long {
-        const int w = (int)blockIdx.x + (i < my_items ? i : my_items - 1) * G;    // past the end: harmless re-reads of the last item
+        const int w = lid + (i < my_items ? i : my_items - 1) * G;    // past the end: harmless re-reads of the last item
         const int hh = (w / nchunk) % H, bb = w / (nchunk * H);
         return (long)bb * S * ld + hh * HD;
     };
@@ -527,7 +539,7 @@ __global__ __launch_bounds__(512, 1) void attentionh8p_kernel(const _Float16* __
     const unsigned long long tk0 = DBG ? __builtin_amdgcn_s_memtime() : 0, tr0 = DBG ? __builtin_amdgcn_s_memrealtime() : 0;
 
     for (int it = 0; it < my_items; ++it) {
-        const int w = (int)blockIdx.x + it * G;
+        const int w = lid + it * G;
         const int ci = w % nchunk;
         const int h = (w / nchunk) % H, b = w / (nchunk * H);
         const long base_off = (long)b * S * ld + h * HD;
