@@ -483,7 +483,7 @@ __global__ __launch_bounds__(512, 1) void gemmh_kernel(const GemmHParams p, cons
 // row maps (searched by brute force over XOR-linear maps; tools/probe notes in DESIGN.md).  For a lane the swizzle is
 // (lane part) ^ (a compile-time even constant K in {0, 2, 4, 6}), so four lane offsets per operand cover every read.
 // Summation order per output element is k ascending by 32, as in the small-tile kernel: bit-identical results whichever runs.
-__global__ __launch_bounds__(512, 1) void gemmh8b_kernel(const GemmHParams p, const int ntn, const int ntiles,
+__global__ __launch_bounds__(512, 1) void gemmh8b_kernel(const GemmHParams p, const int ntn, const int ntiles, const int cgw,
                                                          unsigned long long* dbg) {
 #if defined(__HIP_DEVICE_COMPILE__)
     constexpr int MB = 8, NBW = 4, WM = 128, WN = 64, BM = 256, BN = 256;
@@ -516,11 +516,24 @@ __global__ __launch_bounds__(512, 1) void gemmh8b_kernel(const GemmHParams p, co
     const int dsw = ((drow >> 1) ^ (drow >> 3)) & 7;
     const int voffA = drow * p.lda * 2 + (((lane & 7) ^ dsw) * 16);
     const int voffW = drow * p.ldw * 2 + (((lane & 7) ^ dsw) * 16);
+    // Tile order: column tiles in groups of cgw, row panels inside a group, columns of the group innermost.  The 32 workgroups of
+    // an XCD hold consecutive tiles, i.e. 32 / cgw row panels x the group's cgw column tiles, and every XCD works on the same
+    // group at the same time: the group's W tiles (cgw x 512 KiB at K = 1 024) stay in each L2 while the A panels stream through
+    // once per group.  With the plain row-major order (cgw >= ntn) an N = 3 072 projection cycles 6 MiB of W through a 4 MiB L2.
+    const int ntm = ntiles / ntn;
+    auto tile_rc = [&](int tile, int& rp, int& ct) {
+        const int per_group = ntm * cgw;
+        const int g = tile / per_group, i = tile - g * per_group;
+        const int cg = min(cgw, ntn - cgw * g);
+        rp = i / cg;
+        ct = cgw * g + (i - rp * cg);
+    };
     auto tile_base = [&](int ti, int& a_so, int& w_so) {
         const int t = ti < my_tiles ? ti : my_tiles - 1;          // past the end: harmless re-reads
-        const int tile = lid + t * G;
-        a_so = (tile / ntn) * BM * p.lda * 2;
-        w_so = (tile % ntn) * BN * p.ldw * 2;
+        int rp, ct;
+        tile_rc(lid + t * G, rp, ct);
+        a_so = rp * BM * p.lda * 2;
+        w_so = ct * BN * p.ldw * 2;
     };
     // The two streams run 2 slabs ahead of the MFMAs, so they cross a tile boundary before the MFMAs do: the base of the
     // next tile is taken by a select (no branch: the DMA issue must stay in the MFMA basic block to be interleaved) and
@@ -660,11 +673,12 @@ __global__ __launch_bounds__(512, 1) void gemmh8b_kernel(const GemmHParams p, co
             // wave, through the barrier, until they retire): everything up to W_{g+2} has then landed and the next step
             // needs no wait.  The bias registers are loaded in front of the drain, which covers their latency.
             ks = 0;
-            const int tile = lid + tile_i * G;
+            int t_rp, t_ct;
+            tile_rc(lid + tile_i * G, t_rp, t_ct);
             ++tile_i;
             __builtin_amdgcn_sched_barrier(0);
             f32x4 bv[NBW];
-            const float* bp = p.bias ? p.bias + (tile % ntn) * BN + nbl : nullptr;
+            const float* bp = p.bias ? p.bias + t_ct * BN + nbl : nullptr;
 #pragma unroll
             for (int j = 0; j < NBW; ++j) bv[j] = bp ? *reinterpret_cast<const f32x4*>(bp + CM::blk(j)) : f32x4{0.f, 0.f, 0.f, 0.f};
             unsigned long long te0 = 0, te1 = 0;
@@ -675,7 +689,7 @@ __global__ __launch_bounds__(512, 1) void gemmh8b_kernel(const GemmHParams p, co
             asm volatile("" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
             if (dbg) te1 = __builtin_amdgcn_s_memtime();
-            wave_epilogue<MB, NBW>(p, acc, nullptr, (tile / ntn) * BM + wr * WM, (tile % ntn) * BN + wc * WN, l15, lq, bv);
+            wave_epilogue<MB, NBW>(p, acc, nullptr, t_rp * BM + wr * WM, t_ct * BN + wc * WN, l15, lq, bv);
             tile_base(tile_i + 1, a_nxt, w_nxt);                  // the streams are already inside tile tile_i
             skip = true;
             if (dbg) {
@@ -721,7 +735,11 @@ static hipError_t launch_cfg_h8b(const GemmHParams& p, int num_cus, hipStream_t 
     const int ntm = (p.M + 255) / 256, ntn = p.N / 256;
     const int ntiles = ntm * ntn;
     const int grid = ntiles < num_cus ? ntiles : num_cus;
-    hipLaunchKernelGGL(gemmh8b_kernel, dim3(grid), dim3(512), lds, s, p, ntn, ntiles, g2_dbg_buf);
+    // column tiles walked in groups of four (see the kernel's tile order): M = 66 688, K = 1 024, same box, 50 launches each:
+    // N = 3 072 449-458 -> 439-449 us, N = 2 048 322 -> 310; N = 1 024 is one group either way (groups of 1 / 2: slower); config 5 in
+    // situ, three alternating runs: 10.27-10.33 -> 10.24-10.30 ms/step
+    const int cgw = ntn < 4 ? ntn : 4;
+    hipLaunchKernelGGL(gemmh8b_kernel, dim3(grid), dim3(512), lds, s, p, ntn, ntiles, cgw, g2_dbg_buf);
     return hipGetLastError();
 }
 
