@@ -22,6 +22,7 @@ EXPORTS = [
     "gdx_randn", "gdx_sample_loop", "gdx_bench_ffn_gemm", "gdx_bench_gemm", "gdx_forward_flops", "gdx_profile_begin", "gdx_profile_end", "gdx_bench_attention",
     "gdx_linear_f16", "gdx_linear_f32", "gdx_bench_gemm_f16", "gdx_attention_f16", "gdx_attention_f32", "gdx_plms_update", "gdx_postprocess", "gdx_q_sample_t", "gdx_masked_l2", "gdx_set_graph_replay", "gdx_mfcc",
     "gdx_set_guards", "gdx_check_guards", "gdx_packed_bytes", "gdx_export_packed", "gdx_import_packed", "gdx_set_test_half_dtype",
+    "gdx_set_test_gemmh_tile",
 ]
 
 
@@ -117,6 +118,7 @@ def load():
         "gdx_set_guards": [vp, i32],
         "gdx_check_guards": [vp, C.POINTER(i64), C.POINTER(i32), vp],
         "gdx_set_test_half_dtype": [i32],
+        "gdx_set_test_gemmh_tile": [i32, i32],
         "gdx_packed_bytes": [vp, C.POINTER(i64)],
         "gdx_export_packed": [vp, vp, i64, vp],
         "gdx_import_packed": [vp, vp, i64, vp],

@@ -1345,6 +1345,15 @@ extern "C" int gdx_set_test_half_dtype(int32_t dtype) {
     return 0;
 }
 
+namespace gdx { int g_gemmh_force_mb = -1, g_gemmh_force_nbw = -1; }
+
+extern "C" int gdx_set_test_gemmh_tile(int32_t mb, int32_t nbw) {
+    if (mb < 0 || nbw < 0 || (mb == 0) != (nbw == 0)) return fail("gdx_set_test_gemmh_tile: (mb, nbw) both positive, or (0, 0)");
+    gdx::g_gemmh_force_mb = mb;
+    gdx::g_gemmh_force_nbw = nbw;
+    return 0;
+}
+
 extern "C" int gdx_linear_f16(const float* A, const float* W, const float* bias, float* C32, float* C16, int32_t M,
                               int32_t N, int32_t K, int32_t gelu, void* stream) {
     if (!A || !W || (!C32 && !C16) || M <= 0 || N <= 0 || K <= 0 || K % 64 || N % 64)

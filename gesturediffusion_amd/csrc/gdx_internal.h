@@ -67,6 +67,9 @@ hipError_t launch_gemm2(int omode, int epi, const GemmParams& p, hipStream_t s);
 
 // fp16-input / fp32-accumulate persistent GEMM of the reduced-precision mode (gemmh.hip):
 //   C[row_out][n] = act( sum_k A[m][k] W[n][k] + bias[n] + R[row_out][n] + V[m / T][n] ),  row_out = rowmap ? m + m/T + 1 : m
+// forced tile of launch_gemmh (both half-type builds): -1 = not read yet (GDX_GEMMH_TILE), 0 = the cost model's choice
+extern int g_gemmh_force_mb, g_gemmh_force_nbw;
+
 struct GemmHParams {
     const _Float16* A; int lda;      // [M][K] halves, K % 64 == 0
     const _Float16* W; int ldw;      // packed weight, rows padded to a multiple of 256

@@ -846,11 +846,11 @@ static hipError_t launch_gh_choice(const GemmHParams& p, const GhChoice& c, int 
 hipError_t launch_gemmh(const GemmHParams& p, hipStream_t s) {
     if (!GDX_HNS_NAME::gemmh_supported(p)) return hipErrorInvalidValue;
     const int num_cus = gemm2_num_cus();
-    static int force_mb = -1, force_nbw = -1;
-    if (force_mb < 0) {
-        force_mb = force_nbw = 0;
-        if (const char* e = getenv("GDX_GEMMH_TILE")) sscanf(e, "%d,%d", &force_mb, &force_nbw);
+    if (g_gemmh_force_mb < 0) {
+        g_gemmh_force_mb = g_gemmh_force_nbw = 0;
+        if (const char* e = getenv("GDX_GEMMH_TILE")) sscanf(e, "%d,%d", &g_gemmh_force_mb, &g_gemmh_force_nbw);
     }
+    const int force_mb = g_gemmh_force_mb, force_nbw = g_gemmh_force_nbw;
     static const bool debug = getenv("GDX_GEMM_DEBUG") != nullptr;
     const bool gelu = p.gelu != 0;
     const GhChoice whole = gh_choose(p, p.M, num_cus, force_mb, force_nbw);

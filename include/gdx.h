@@ -316,6 +316,10 @@ int gdx_attention_f16(const float* qkv, float* ctx, int32_t B, int32_t S, int32_
 /* element type (GDX_DTYPE_F16, the default, or GDX_DTYPE_BF16) of the stand-alone entry points gdx_linear_f16,
  * gdx_attention_f16, gdx_bench_gemm_f16 and gdx_bench_attention's reduced-precision version; process-wide, tests only */
 int gdx_set_test_half_dtype(int32_t dtype);
+/* tile shape of the reduced-precision GEMM (csrc/gemmh.hip) for every later call: 16 * mb rows x 64 * nbw columns, (16, 4) = the
+ * 256 x 256 eight-wave kernel with its grouped tile order, (0, 0) = back to the cost model (which also re-enables the row cut).
+ * Same effect as the GDX_GEMMH_TILE=mb,nbw environment variable of the measurement tools; process-wide, tests only */
+int gdx_set_test_gemmh_tile(int32_t mb, int32_t nbw);
 /* ctx = softmax(Q K^T / sqrt(hd)) V per (sample, head) through the fp32 attention kernels: the SDPA inside
  * nn.MultiheadAttention of the encoder layers (model/mdm.py:90-96).  qkv [B*S][3d], ctx [B*S][d] fp32 device arrays.
  * version 0 = the choice gdx_forward makes, 1 = 32x32-block kernel (attention.hip, the general fallback),

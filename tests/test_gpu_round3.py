@@ -226,3 +226,42 @@ def test_packed_image_is_never_replaced_by_the_untouched_parameters():
     b.load_state_dict(sd, strict=False)
     b.compute_dtype = "fp16"
     assert rel_err(_fwd(b, cfg).cpu(), _fwd(a, cfg).cpu()) < 2e-2    # now packed from real parameters, in fp16
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# fp16 256 x 256 GEMM: column tiles walked in groups of four (gemmh.hip, round 3).  The order is a re-numbering of the
+# tiles, so the only thing that can go wrong is a tile computed twice / never: every output element is checked.
+@pytest.mark.parametrize("M,N,K,gelu", [(5000, 3072, 256, 0),     # 12 column tiles = three full groups, one round
+                                        (9100, 2304, 256, 1),     # 9 = 4 + 4 + 1, 324 tiles: more than one round, ragged last panel
+                                        (6000, 1280, 512, 0),     # 5 = 4 + 1
+                                        (70000, 1536, 256, 0),    # 6 = 4 + 2, 1 644 tiles = 6.4 rounds per CU
+                                        (3000, 1024, 1024, 0)])   # one group (the plain order)
+def test_fp16_gemm_grouped_tile_order_covers_every_tile(M, N, K, gelu):
+    import ctypes as C
+    from gesturediffusion_amd import _lib
+    lib = _lib.load()
+    d = dev()
+    g = torch.Generator(device=d).manual_seed(M + N)
+    A = torch.randn(M, K, device=d, generator=g)
+    W = torch.randn(N, K, device=d, generator=g) / K ** 0.5
+    b = torch.randn(N, device=d, generator=g)
+    vp = lambda t: C.c_void_p(t.data_ptr())   # noqa: E731
+    s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    outs = []
+    try:
+        for tile in ((16, 4), (0, 0)):                      # the eight-wave kernel on every row, then the cost model's choice
+            _lib.check(lib.gdx_set_test_gemmh_tile(*tile), lib)
+            C32 = torch.full((M, N), float("nan"), device=d)
+            _lib.check(lib.gdx_linear_f16(vp(A), vp(W), vp(b), vp(C32), None, M, N, K, gelu, s), lib)
+            outs.append(C32)
+    finally:
+        _lib.check(lib.gdx_set_test_gemmh_tile(0, 0), lib)
+    assert not torch.isnan(outs[0]).any()
+    # every kernel of gemmh.hip sums k ascending by 32: whichever tile shape runs, the bits are the same
+    assert torch.equal(outs[0], outs[1])
+    rows = torch.randperm(M, device=d)[:2048]
+    ref = A[rows].half().double() @ W.half().double().t() + b.double()
+    if gelu:
+        ref = torch.nn.functional.gelu(ref)
+    err = float(((outs[0][rows].double() - ref).abs().max() / ref.abs().max()).item())
+    assert err < (3e-5 if gelu else 2e-6)
