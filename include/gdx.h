@@ -107,7 +107,10 @@ int gdx_import_packed(gdx_handle_t h, const void* host, int64_t bytes, void* str
 /* ---- per-problem set-up ---------------------------------------------------------------- */
 /* Size the workspace for `batch` samples of `frames` frames (allocates; not capturable).
  * V2 requires frames % window == 0 (the reference's einops rearrange raises,
- * model/local_attention.py:104,110). */
+ * model/local_attention.py:104,110).  The GEMMs address their operands through 32-bit buffer offsets: a forward whose
+ * largest operand (rows x 3 * latent_dim, or rows x ff_size, in the compute dtype) reaches 2 GiB fails with "an operand
+ * exceeds the 2 GiB buffer-descriptor range; run the batch in smaller pieces" -- fp32 at the BASELINE width: a little
+ * under 3 000 samples of 197 tokens in ONE call (bench.py --config 4 runs its 2 048 samples as sub-batches of 256). */
 int gdx_prepare(gdx_handle_t h, int32_t batch, int32_t frames);
 
 /* Step-invariant conditioning (hoisted out of the 1000-step loop): seed-pose embedding for the
