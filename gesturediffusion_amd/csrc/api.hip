@@ -827,7 +827,7 @@ static int gemm_f16(bool bf, const _Float16* A, int lda, const Packed& P, const 
                     const float* V, int ldv, float* C32, int ldc32, _Float16* C16, int ldc16, int M, int N, int T,
                     int rowmap, int gelu, hipStream_t s) {
     const size_t ab = (size_t)M * lda * 2, wb = (size_t)P.npad16 * P.kpad16 * 2;
-    if (ab >= (1ull << 31) || wb >= (1ull << 31)) return fail("gemm_f16: operand exceeds the 2 GiB buffer-descriptor range");
+    if (ab >= (1ull << 31) || wb >= (1ull << 31)) return fail("gemm_f16: an operand exceeds the 2 GiB buffer-descriptor range; run the batch in smaller pieces");
     if (N > P.npad16) return fail("gemm_f16: N exceeds the packed weight");
     GemmHParams p{A, lda, P.w16, P.kpad16, (int)ab, (int)wb, bias, R, ldr, V, ldv, C32, ldc32, C16, ldc16,
                   M, N, P.kpad16, T, rowmap, gelu};
@@ -1360,6 +1360,8 @@ extern "C" int gdx_linear_f16(const float* A, const float* W, const float* bias,
         return fail("gdx_linear_f16: bad argument");
     hipStream_t s = (hipStream_t)stream;
     const int npad = round_up(N, 256);
+    if (2 * (size_t)M * K >= (1ull << 31) || 2 * (size_t)npad * K >= (1ull << 31))
+        return fail("gdx_linear_f16: an operand exceeds the 2 GiB buffer-descriptor range; run the batch in smaller pieces");
     _Float16 *a16 = nullptr, *w16 = nullptr, *c16 = nullptr;
     std::vector<void*> pool;
     int rc = 0;
@@ -1437,6 +1439,8 @@ extern "C" int gdx_bench_gemm_f16(int32_t M, int32_t N, int32_t K, int32_t gelu,
     if (!avg_us || M <= 0 || N <= 0 || K <= 0 || K % 64 || N % 64 || iters <= 0) return fail("gdx_bench_gemm_f16: bad argument");
     hipStream_t s = (hipStream_t)stream;
     const int npad = round_up(N, 256);
+    if (2 * (size_t)M * K >= (1ull << 31) || 2 * (size_t)npad * K >= (1ull << 31))
+        return fail("gdx_bench_gemm_f16: an operand exceeds the 2 GiB buffer-descriptor range");
     float *Af = nullptr, *bias = nullptr;
     _Float16 *a16 = nullptr, *w16 = nullptr, *c16 = nullptr;
     std::vector<void*> pool;

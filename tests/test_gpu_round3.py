@@ -265,3 +265,35 @@ def test_fp16_gemm_grouped_tile_order_covers_every_tile(M, N, K, gelu):
         ref = torch.nn.functional.gelu(ref)
     err = float(((outs[0][rows].double() - ref).abs().max() / ref.abs().max()).item())
     assert err < (3e-5 if gelu else 2e-6)
+
+
+def test_gemm_operand_beyond_2gib_is_a_loud_error_in_both_precisions():
+    """The persistent GEMMs address operands through 32-bit buffer offsets.  Round 2 silently dropped to another kernel (other bits
+    for the same rows) beyond 2 GiB; since round 3 the call fails and says what to do (include/gdx.h at gdx_prepare)."""
+    import ctypes as C
+    from gesturediffusion_amd import _lib
+    lib = _lib.load()
+    d = dev()
+    vp = lambda t: C.c_void_p(t.data_ptr())   # noqa: E731
+    s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    K, N = 512, 64
+    W = torch.randn(N, K, device=d)
+    b = torch.zeros(N, device=d)
+    M32 = (1 << 31) // (K * 4) + 1024                      # A alone is past 2 GiB in fp32
+    A = torch.zeros(M32, K, device=d)
+    out = torch.empty(M32, N, device=d)
+    with pytest.raises(_lib.GdxError, match="2 GiB"):
+        _lib.check(lib.gdx_linear_f32(vp(A), vp(W), vp(b), None, vp(out), M32, N, K, 0, 0, 0, 0, s), lib)
+    M16 = (1 << 31) // (K * 2) + 1024                      # ... and in the 16-bit modes (the fp32 staging copy is twice that)
+    del A, out
+    A = torch.zeros(M16, K, device=d)
+    out = torch.empty(M16, N, device=d)
+    with pytest.raises(_lib.GdxError, match="2 GiB"):
+        _lib.check(lib.gdx_linear_f16(vp(A), vp(W), vp(b), vp(out), None, M16, N, K, 0, s), lib)
+    # just below the limit the same calls work
+    M_ok = 3_000_000 // 4
+    A = torch.randn(M_ok, K, device=d)
+    out = torch.full((M_ok, N), float("nan"), device=d)
+    _lib.check(lib.gdx_linear_f32(vp(A), vp(W), vp(b), None, vp(out), M_ok, N, K, 0, 0, 0, 0, s), lib)
+    ref = A[-1000:].double() @ W.double().t()
+    assert rel_err(out[-1000:].cpu().double(), ref.cpu()) < 3e-6
