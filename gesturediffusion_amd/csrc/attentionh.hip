@@ -4,7 +4,9 @@
 //
 // Structure: one 512-thread workgroup per (sample, head, query chunk) -- or, persistent, per CU walking such items; all eight
 // waves compute, each keeps one or two query blocks of 16 resident (Q fragments + O^T accumulators in registers), walks all
-// K/V tiles of 32 keys once and issues 1/8 of every tile's LDS-DMA into a 4-stage ring (counted vmcnt, raw barriers).
+// K/V tiles of 32 keys once and issues 1/8 of every tile's LDS-DMA into a 3-stage ring (counted vmcnt, raw barriers); behind the
+// ring every wave owns a 16-row slice of LDS through which its Q fragments arrive and its output blocks leave as WHOLE ROWS
+// (round 3: loaded / stored in the fragment layout they were 6 144 partial-line requests per workgroup and item).
 // (The first kernel of this file, 4 compute + 4 loader waves, was removed in round 3; restructures that were measured and
 // not kept -- one wave per SIMD with 512 registers, SIMD partners rotated by half a tile -- are recorded in
 // profiles/r03b_fp16_attention_experiments.txt.)
@@ -260,7 +262,7 @@ __global__ __launch_bounds__(512, 1) void attentionh8q_kernel(const _Float16* __
 #if defined(__HIP_DEVICE_COMPILE__)
     constexpr int ROWB = HD * 2, CPR = ROWB / 16, T_BYTES = 32 * ROWB, STAGE_BYTES = 2 * T_BYTES;
     constexpr int T_P = T_BYTES / 1024, P = 2 * T_P, PW = (P + 7) / 8;
-    constexpr int NST = 4;
+    constexpr int NST = 3;
     constexpr int NKS = HD / 32, NNB = HD / 16;
     constexpr float RESCALE_THR = 8.0f;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -281,16 +283,37 @@ __global__ __launch_bounds__(512, 1) void attentionh8q_kernel(const _Float16* __
     const int mine = wave < nblk ? min((nblk - wave + 7) / 8, QB) : 0;   // blocks qb_lo + wave + 8*qi
     auto fswz = [](int row) { return HD == 32 ? ((row >> 2) & 1) << 1 : HD == 64 ? ((row >> 1) & 3) << 1 : (row & 7) << 1; };
 
+    // Q fragments and output blocks travel as WHOLE ROWS through the wave's own 16-row slice of LDS (behind the K/V ring).
+    // Loaded straight into the fragment layout a Q load instruction takes 64 bytes from each of 16 rows, and an output store puts
+    // 32 bytes into each of 16 rows: 6 144 partial-line requests per workgroup and item, which the CU's address unit serves at
+    // about two cycles each -- round-3 stamps: 6-10 k cycles to ISSUE a wave's 16 Q loads and 5.9 k for its 32 stores, ~13 us per
+    // item outside the tile loop.  A query block is 16 rows of ROWB bytes, exactly a 16-key K block: staged by LDS-DMA with K's
+    // chunk swizzle it is read back with K's fragment read; an output block is written to the slice in the accumulator layout
+    // (chunk-swizzled by row) and leaves as 16-byte pieces of whole rows.
+    constexpr int RPP = 1024 / ROWB;                                    // rows per 1 KiB piece (16 at head_dim 32)
+    constexpr int NPQ = 16 / RPP;                                       // pieces per 16-row block
+    char* sl = smem + NST * STAGE_BYTES + wave * (16 * ROWB);
+    const int kbase = l15 * ROWB + ((lq ^ fswz(l15)) << 4);
+    const auto rsrcQ = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(base), (short)0, ah_records(qkv_bytes - base_off * 2), 0x00020000);
+    auto dma_q = [&](int qi) {                                          // rows past S: the next sample's / zeros, their columns are never stored
+        const int q0 = 16 * (qb_lo + wave + 8 * qi);
+#pragma unroll
+        for (int j = 0; j < NPQ; ++j) {
+            const int row = j * RPP + lane / CPR;
+            const int vo = (int)((q0 + row) * ld * 2) + (((lane % CPR) ^ fswz(row)) * 16);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcQ, (lds_ptr_t)(sl + j * 1024), 16, vo, 0, 0, 0);
+        }
+    };
     f16x8 qf[QB][NKS];
+    auto read_q = [&](int qi) {
 #pragma unroll
-    for (int qi = 0; qi < QB; ++qi) {
-        int q = 16 * (qb_lo + wave + 8 * qi) + l15;
-        q = q < S ? q : S - 1;
-        const _Float16* qp = base + (long)q * ld + 8 * lq;
+        for (int ks = 0; ks < NKS; ++ks) qf[qi][ks] = *reinterpret_cast<const f16x8*>(sl + (kbase ^ (ks << 6)));
+    };
 #pragma unroll
-        for (int ks = 0; ks < NKS; ++ks) qf[qi][ks] = *reinterpret_cast<const f16x8*>(qp + 32 * ks);
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    for (int qi = 0; qi < QB; ++qi)
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) qf[qi][ks] = f16x8{0, 0, 0, 0, 0, 0, 0, 0};
+    if (mine > 0) dma_q(0);                                             // block 0 travels with the ring fill below
 
     const long kb_off = (base_off + d) * 2, vb_off = (base_off + 2 * d) * 2;
     const auto rsrcK = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(base + d), (short)0, ah_records(qkv_bytes - kb_off), 0x00020000);
@@ -329,13 +352,20 @@ __global__ __launch_bounds__(512, 1) void attentionh8q_kernel(const _Float16* __
         m_run[qi] = -INFINITY;
         l_run[qi] = 0.0f;
     }
-    const int kbase = l15 * ROWB + ((lq ^ fswz(l15)) << 4);
     const int vrow = 4 * lq + (l15 >> 2);
     const int vbase = T_BYTES + vrow * ROWB + ((fswz(vrow) >> 1) << 5) + (l15 & 3) * 8;
 
 #pragma unroll
     for (int s = 0; s < NST - 1; ++s) issue(s);
-    ah_wait_vm<(NST - 2) * PW>();
+    ah_wait_vm<0>();
+    if (mine > 0) read_q(0);
+    if (mine > 1) {                                                     // the slice is reused once block 0 is in registers
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        asm volatile("" ::: "memory");
+        dma_q(1);
+        ah_wait_vm<0>();
+        read_q(1);
+    }
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     int stage = 0, wst = NST - 1;
@@ -430,6 +460,9 @@ __global__ __launch_bounds__(512, 1) void attentionh8q_kernel(const _Float16* __
     else if (mine == 1) run_tiles(std::integral_constant<int, 1>{});
     else run_tiles(std::integral_constant<int, 0>{});
     ah_wait_vm<0>();
+    // output: a lane holds columns 16 nb + 4 lq .. + 3 of query l15; through the slice (16-byte chunk c of row r at c ^ (r mod
+    // chunks-per-row, at most 16): the sixteen rows of a column land in sixteen different bank groups) and out as whole rows
+    constexpr int GM = CPR < 16 ? CPR - 1 : 15;
 #pragma unroll
     for (int qi = 0; qi < QB; ++qi) {
         if (qi >= mine) continue;
@@ -437,14 +470,18 @@ __global__ __launch_bounds__(512, 1) void attentionh8q_kernel(const _Float16* __
         l_tot += __shfl_xor(l_tot, 16);
         l_tot += __shfl_xor(l_tot, 32);
         const float inv = 1.0f / l_tot;
-        const int q = 16 * (qb_lo + wave + 8 * qi) + l15;
-        if (q < S) {
-            _Float16* op = ctx + ((long)b * S + q) * d + h * HD + 4 * lq;
 #pragma unroll
-            for (int nb = 0; nb < NNB; ++nb) {
-                const f32x4 r = o[qi][nb] * inv;
-                *reinterpret_cast<f16x4*>(op + 16 * nb) = f16x4{(half_t)r[0], (half_t)r[1], (half_t)r[2], (half_t)r[3]};
-            }
+        for (int nb = 0; nb < NNB; ++nb) {
+            const f32x4 r = o[qi][nb] * inv;
+            *reinterpret_cast<f16x4*>(sl + l15 * ROWB + (((2 * nb + (lq >> 1)) ^ (l15 & GM)) << 4) + (lq & 1) * 8) =
+                f16x4{(half_t)r[0], (half_t)r[1], (half_t)r[2], (half_t)r[3]};
+        }
+        const int q0 = 16 * (qb_lo + wave + 8 * qi);
+#pragma unroll
+        for (int j = 0; j < NPQ; ++j) {
+            const int row = j * RPP + lane / CPR, c = lane % CPR;
+            const f16x8 v = *reinterpret_cast<const f16x8*>(sl + row * ROWB + ((c ^ (row & GM)) << 4));
+            if (q0 + row < S) *reinterpret_cast<f16x8*>(ctx + ((long)b * S + q0 + row) * d + h * HD + 8 * c) = v;
         }
     }
 #endif
@@ -466,7 +503,7 @@ __global__ __launch_bounds__(512, 1) void attentionh8p_kernel(const _Float16* __
 #if defined(__HIP_DEVICE_COMPILE__)
     constexpr int ROWB = HD * 2, CPR = ROWB / 16, T_BYTES = 32 * ROWB, STAGE_BYTES = 2 * T_BYTES;
     constexpr int T_P = T_BYTES / 1024, P = 2 * T_P, PW = (P + 7) / 8;
-    constexpr int NST = 4;
+    constexpr int NST = 3;
     constexpr int NKS = HD / 32, NNB = HD / 16;
     constexpr float RESCALE_THR = 8.0f;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -527,9 +564,62 @@ __global__ __launch_bounds__(512, 1) void attentionh8p_kernel(const _Float16* __
     const int vrow = 4 * lq + (l15 >> 2);
     const int vbase = T_BYTES + vrow * ROWB + ((fswz(vrow) >> 1) << 5) + (l15 & 3) * 8;
 
+    // Q fragments and output blocks travel as whole rows through the wave's 16-row slice of LDS (see attentionh8q_kernel).  Item
+    // i + 1's fragments are fetched at the END of item i, once its accumulators are packed to 16 bits, and IN FRONT of its output
+    // stores: vector-memory operations retire in order, and nothing should have to wait for a store's acknowledgement.
+    constexpr int RPP = 1024 / ROWB, NPQ = 16 / RPP, GM = CPR < 16 ? CPR - 1 : 15;
+    char* sl = smem + NST * STAGE_BYTES + wave * (16 * ROWB);
+    f16x8 qf[QB][NKS];
+    auto item_geom = [&](int i, long& off, int& qb_lo, int& mine, int& b, int& h) {
+        // (integer division runs on the vector ALU: without the readfirstlanes these wave-uniform results sit in vector registers
+        //  through the whole tile loop, which has none to spare)
+        const int w = lid + i * G;
+        const int ci = __builtin_amdgcn_readfirstlane(w % nchunk);
+        h = __builtin_amdgcn_readfirstlane((w / nchunk) % H);
+        b = __builtin_amdgcn_readfirstlane(w / (nchunk * H));
+        off = (long)b * S * ld + h * HD;
+        qb_lo = __builtin_amdgcn_readfirstlane((int)((long)ci * nqb / nchunk));
+        const int nblk = __builtin_amdgcn_readfirstlane((int)((long)(ci + 1) * nqb / nchunk)) - qb_lo;   // <= 8 * QB
+        mine = wave < nblk ? min((nblk - wave + 7) / 8, QB) : 0;         // blocks qb_lo + wave + 8*qi
+    };
+    auto load_q = [&](int i) {
+        long off;
+        int qb_lo, mine, b, h;
+        item_geom(i, off, qb_lo, mine, b, h);
+        const auto rsrcQ = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(qkv + off), (short)0, ah_records(qkv_bytes - off * 2), 0x00020000);
+        int ln = lane;                                                  // laundered: per-lane address arithmetic derived from it stays
+        asm volatile("" : "+v"(ln));                                    // here instead of being hoisted out of the item loop (and spilled)
+        const int kb2 = (ln & 15) * ROWB + (((ln >> 4) ^ fswz(ln & 15)) << 4);
+#pragma unroll
+        for (int qi = 0; qi < QB; ++qi) {
+            if (qi >= mine) {                                           // wave-uniform.  (Every fragment register is written on every
+#pragma unroll                                                          //  path: a conditionally kept one stays live through the
+                for (int ks = 0; ks < NKS; ++ks) qf[qi][ks] = f16x8{0, 0, 0, 0, 0, 0, 0, 0};   // epilogue, beside O and its packed copy: spills)
+                continue;
+            }
+            const int q0 = 16 * (qb_lo + wave + 8 * qi);
+            __builtin_amdgcn_s_waitcnt(0xc07f);                          // the slice's previous reads
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int j = 0; j < NPQ; ++j) {
+                const int row = j * RPP + ln / CPR;
+                const int vo = (int)((q0 + row) * ld * 2) + (((ln % CPR) ^ fswz(row)) * 16);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcQ, (lds_ptr_t)(sl + j * 1024), 16, vo, 0, 0, 0);
+            }
+            ah_wait_vm<0>();
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks) qf[qi][ks] = *reinterpret_cast<const f16x8*>(sl + (kb2 ^ (ks << 6)));
+        }
+    };
+#pragma unroll
+    for (int qi = 0; qi < QB; ++qi)
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) qf[qi][ks] = f16x8{0, 0, 0, 0, 0, 0, 0, 0};
+
 #pragma unroll
     for (int s = 0; s < NST - 1; ++s) issue(s);
-    ah_wait_vm<(NST - 2) * PW>();
+    load_q(0);
+    ah_wait_vm<0>();
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     int stage = 0, wst = NST - 1;
@@ -539,24 +629,10 @@ __global__ __launch_bounds__(512, 1) void attentionh8p_kernel(const _Float16* __
     const unsigned long long tk0 = DBG ? __builtin_amdgcn_s_memtime() : 0, tr0 = DBG ? __builtin_amdgcn_s_memrealtime() : 0;
 
     for (int it = 0; it < my_items; ++it) {
-        const int w = lid + it * G;
-        const int ci = w % nchunk;
-        const int h = (w / nchunk) % H, b = w / (nchunk * H);
-        const long base_off = (long)b * S * ld + h * HD;
-        const _Float16* base = qkv + base_off;
-        const int qb_lo = (int)((long)ci * nqb / nchunk), qb_hi = (int)((long)(ci + 1) * nqb / nchunk);
-        const int nblk = qb_hi - qb_lo;                                   // <= 8 * QB
-        const int mine = wave < nblk ? min((nblk - wave + 7) / 8, QB) : 0;   // blocks qb_lo + wave + 8*qi
+        long base_off;
+        int qb_lo, mine, b, h;
+        item_geom(it, base_off, qb_lo, mine, b, h);
 
-        f16x8 qf[QB][NKS];
-#pragma unroll
-        for (int qi = 0; qi < QB; ++qi) {
-            int q = 16 * (qb_lo + wave + 8 * qi) + l15;
-            q = q < S ? q : S - 1;
-            const _Float16* qp = base + (long)q * ld + 8 * lq;
-#pragma unroll
-            for (int ks = 0; ks < NKS; ++ks) qf[qi][ks] = *reinterpret_cast<const f16x8*>(qp + 32 * ks);
-        }
         f32x4 o[QB][NNB];
         float m_run[QB], l_run[QB];
 #pragma unroll
@@ -662,6 +738,21 @@ __global__ __launch_bounds__(512, 1) void attentionh8p_kernel(const _Float16* __
         if (mine == 2) run_tiles(std::integral_constant<int, 2>{});
         else if (mine == 1) run_tiles(std::integral_constant<int, 1>{});
         else run_tiles(std::integral_constant<int, 0>{});
+        // the next item's fragments go into the registers of this item's (dead after the last tile), while the accumulators are
+        // still where the MFMAs left them
+        asm volatile("" ::: "memory");
+        if (it + 1 < my_items) {
+            load_q(it + 1);                                               // in front of the stores
+        } else {
+#pragma unroll
+            for (int qi = 0; qi < QB; ++qi)
+#pragma unroll
+                for (int ks = 0; ks < NKS; ++ks) qf[qi][ks] = f16x8{0, 0, 0, 0, 0, 0, 0, 0};
+        }
+        asm volatile("" ::: "memory");
+        int ln = lane;
+        asm volatile("" : "+v"(ln));                                      // (as in load_q)
+        const int e15 = ln & 15, eq = ln >> 4;
 #pragma unroll
         for (int qi = 0; qi < QB; ++qi) {
             if (qi >= mine) continue;
@@ -669,14 +760,18 @@ __global__ __launch_bounds__(512, 1) void attentionh8p_kernel(const _Float16* __
             l_tot += __shfl_xor(l_tot, 16);
             l_tot += __shfl_xor(l_tot, 32);
             const float inv = 1.0f / l_tot;
-            const int q = 16 * (qb_lo + wave + 8 * qi) + l15;
-            if (q < S) {
-                _Float16* op = ctx + ((long)b * S + q) * d + h * HD + 4 * lq;
 #pragma unroll
-                for (int nb = 0; nb < NNB; ++nb) {
-                    const f32x4 r = o[qi][nb] * inv;
-                    *reinterpret_cast<f16x4*>(op + 16 * nb) = f16x4{(half_t)r[0], (half_t)r[1], (half_t)r[2], (half_t)r[3]};
-                }
+            for (int nb = 0; nb < NNB; ++nb) {
+                const f32x4 r = o[qi][nb] * inv;
+                *reinterpret_cast<f16x4*>(sl + e15 * ROWB + (((2 * nb + (eq >> 1)) ^ (e15 & GM)) << 4) + (eq & 1) * 8) =
+                    f16x4{(half_t)r[0], (half_t)r[1], (half_t)r[2], (half_t)r[3]};
+            }
+            const int q0 = 16 * (qb_lo + wave + 8 * qi);
+#pragma unroll
+            for (int j = 0; j < NPQ; ++j) {
+                const int row = j * RPP + ln / CPR, c = ln % CPR;
+                const f16x8 v = *reinterpret_cast<const f16x8*>(sl + row * ROWB + ((c ^ (row & GM)) << 4));
+                if (q0 + row < S) *reinterpret_cast<f16x8*>(ctx + ((long)b * S + q0 + row) * d + h * HD + 8 * c) = v;
             }
         }
     }
@@ -692,7 +787,7 @@ __global__ __launch_bounds__(512, 1) void attentionh8p_kernel(const _Float16* __
 template <int HD>
 static hipError_t launch_ah8p(const _Float16* qkv, _Float16* ctx, int B, int S, int H, int d, long qkv_bytes, int num_cus,
                               hipStream_t s) {
-    const size_t lds = (size_t)4 * 2 * 32 * HD * 2;
+    const size_t lds = (size_t)3 * 2 * 32 * HD * 2 + (size_t)8 * 16 * HD * 2;   // three K/V stages + a 16-row slice per wave
     static bool attr_done = false;
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attentionh8p_kernel<HD, 2, false>),
@@ -719,7 +814,7 @@ static hipError_t launch_ah8p(const _Float16* qkv, _Float16* ctx, int B, int S, 
 
 template <int HD>
 static hipError_t launch_ah8q(const _Float16* qkv, _Float16* ctx, int B, int S, int H, int d, long qkv_bytes, hipStream_t s) {
-    const size_t lds = (size_t)4 * 2 * 32 * HD * 2;
+    const size_t lds = (size_t)3 * 2 * 32 * HD * 2 + (size_t)8 * 16 * HD * 2;   // three K/V stages + a 16-row slice per wave
     static bool attr_done = false;
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attentionh8q_kernel<HD, 2>),
