@@ -860,6 +860,7 @@ hipError_t launch_attentionh(const _Float16* qkv, _Float16* ctx, int B, int S, i
     // measured (tools/attnh_one.py, us): B=128 S=521 hd=256: 8 waves x 1 block 373, 8 waves x 2 blocks 292, persistent 273-285;
     // B=16 (config 5's per-GPU share): 58.9 / 37.4;  B=64 S=197 hd=128: 19.9 / 18.7.  The 8 x 2 kernels need enough
     // workgroups to fill the chip (they make half as many), so small problems keep one block per wave.
+    // (Round 3, XCD-aware items + whole-row Q / output traffic: persistent 257-261, B=16 33.0, B=256 S=197 hd=128 55.7.)
     const int nqb = (S + 15) / 16;
     const long nitems = (long)B * H * ((nqb + 15) / 16);
     const int num_cus = gemm2_num_cus();
